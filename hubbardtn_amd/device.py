@@ -1,0 +1,113 @@
+"""Device primitives of the hot path: thin wrapper over the C ABI (hubbardtn_amd/abi.py).
+
+PyTorch is used only as plumbing: device memory (torch tensors), the current HIP stream and
+(in dist.py) torch.distributed.  Every compute call below goes through libhubbardtn_hip.so;
+if the library or the GPU is missing, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class HipOps:
+    """the one and only implementation of the device primitives used by the product path"""
+
+    name = "hip"
+
+    def __init__(self, device: int = 0):
+        import torch
+        self.torch = torch
+        self.lib = abi.load_library()
+        if not torch.cuda.is_available():
+            raise abi.HtnError("no HIP device visible: hubbardtn_amd has no CPU fallback")
+        torch.cuda.set_device(device)
+        self.device = torch.device("cuda", device)
+        name = C.create_string_buffer(256)
+        cus = C.c_int(0)
+        abi.check(self.lib, self.lib.htn_device_init(device, name, C.byref(cus)), "htn_device_init")
+        self.arch = name.value.decode()
+        self.cu_count = cus.value
+        self._dots_scratch = None
+
+    # ---- memory -----------------------------------------------------------------------------
+    def empty_z(self, n):
+        return self.torch.empty(int(n), dtype=self.torch.complex128, device=self.device)
+
+    def zeros_z(self, n):
+        return self.torch.zeros(int(n), dtype=self.torch.complex128, device=self.device)
+
+    def empty_f64(self, n):
+        return self.torch.empty(int(n), dtype=self.torch.float64, device=self.device)
+
+    def empty_i32(self, n):
+        return self.torch.empty(int(n), dtype=self.torch.int32, device=self.device)
+
+    def to_device(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype.fields is not None:            # struct arrays travel as bytes
+            return self.torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+        return self.torch.from_numpy(arr.copy()).to(self.device)
+
+    def to_host(self, t) -> np.ndarray:
+        return t.cpu().numpy()
+
+    def copy_(self, dst, src):
+        dst.copy_(src)
+
+    def zero(self, t):
+        t.zero_()
+
+    def sync(self):
+        self.torch.cuda.current_stream().synchronize()
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(0 if t is None else t.data_ptr())
+
+    # ---- kernels ----------------------------------------------------------------------------
+    def upload_tasks(self, tasks):
+        """tasks: planner.Tasks -> (tiles_dev, ntiles, segs_dev)"""
+        return (self.to_device(tasks.tiles), tasks.ntiles, self.to_device(tasks.segs))
+
+    def grouped_gemm(self, bufs, dev_tasks):
+        tiles, ntiles, segs = dev_tasks
+        if ntiles == 0:
+            return
+        table = (C.c_void_p * abi.HTN_MAX_BUFS)(*[0 if b is None else b.data_ptr() for b in bufs])
+        abi.check(self.lib, self.lib.htn_grouped_gemm_z(table, self._p(tiles), ntiles, self._p(segs),
+                                                        self._stream()), "htn_grouped_gemm_z")
+
+    def dots(self, V, ldv, nvec, w, n, out):
+        need = self.lib.htn_dots_scratch_elems(64)
+        if self._dots_scratch is None or self._dots_scratch.numel() < need:
+            self._dots_scratch = self.empty_z(need)
+        assert nvec <= 64
+        abi.check(self.lib, self.lib.htn_dots_z(self._p(V), ldv, nvec, self._p(w), n, self._p(out),
+                                                self._p(self._dots_scratch), self._stream()), "htn_dots_z")
+
+    def axpys(self, w, V, ldv, nvec, coef, sign, n):
+        abi.check(self.lib, self.lib.htn_axpys_z(self._p(w), self._p(V), ldv, nvec, self._p(coef), float(sign),
+                                                 n, self._stream()), "htn_axpys_z")
+
+    def scale_inv_sqrt(self, dst, src, nrm2, n):
+        abi.check(self.lib, self.lib.htn_scale_inv_sqrt_z(self._p(dst), self._p(src), self._p(nrm2), n,
+                                                          self._stream()), "htn_scale_inv_sqrt_z")
+
+    def jacobi_svd(self, G, Vj, S, desc_dev, nblocks, max_m, max_sweeps, tol, info):
+        abi.check(self.lib, self.lib.htn_jacobi_svd_z(self._p(G), self._p(Vj), self._p(S), self._p(desc_dev),
+                                                      nblocks, max_m, max_sweeps, float(tol), self._p(info),
+                                                      self._stream()), "htn_jacobi_svd_z")
+
+    def batched_copy(self, dst, src, idx, scl, items_dev, nitems, gscale):
+        if nitems == 0:
+            return
+        abi.check(self.lib, self.lib.htn_batched_copy_z(self._p(dst), self._p(src), self._p(idx), self._p(scl),
+                                                        self._p(items_dev), nitems, float(gscale),
+                                                        self._stream()), "htn_batched_copy_z")

@@ -1,0 +1,331 @@
+"""Two-site DMRG sweep engine (finite chain) on the device primitives of hubbardtn_hip.h.
+
+Stands in for MPSKit's two-site sweep body reached from
+`find_groundstate(psi0, H, IDMRG2(; trscheme, tol))` (src/HubbardFunctions.jl:1010) -- per bond:
+form theta, Lanczos lowest eigenpair of the AC2 effective Hamiltonian, SVD + truncation, write
+back, move the environment.  The sweep schedule follows MPSKit's DMRG2:
+bonds 1..L-1 going right, then L-2..1 going left (2L-3 bond updates per sweep).
+
+All tensors stay on the device between bonds; the host sees only the Lanczos tridiagonal
+coefficients and the singular values (needed for the global truncation rule, App. A.6).
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import planner as pl
+from .planner import (BUF_AUX, BUF_L, BUF_R, BUF_S1, BUF_S2, BUF_X, BUF_Y, BUF_Z, Bond, EnvLayout, SiteLayout,
+                      ThetaLayout)
+
+
+@dataclass
+class BondStats:
+    bond: int
+    direction: int
+    energy: float
+    n_matvec: int
+    residual: float
+    trunc_weight: float
+    chi_full: int
+    multiplets: int
+    theta_size: int
+    apply_flops: int
+    apply_bytes: int
+    svd_flops: int
+    jacobi_sweeps: int
+    n_tiles: int
+    n_segs: int
+    t_plan: float = 0.0
+    t_total: float = 0.0
+
+
+def _tridiag_lowest(alphas, betas):
+    k = len(alphas)
+    T = np.diag(np.asarray(alphas, dtype=float))
+    for i in range(k - 1):
+        T[i, i + 1] = T[i + 1, i] = betas[i]
+    w, v = np.linalg.eigh(T)
+    return float(w[0]), v[:, 0]
+
+
+class DMRG2:
+    """finite two-site DMRG on reduced SU(2) x U(1) tensors.
+
+    ops        : device primitive provider (hubbardtn_amd.device.HipOps in the product)
+    mpo        : list[models.MPOSite]
+    bonds      : list of {sector: count} for bonds 0..L (initial state)
+    tensors    : list of {(l, s, r): ndarray[n_l, n_r]} right-canonical initial site tensors
+    chi_full   : truncdim(D) in TensorKit's `dim` units (sum (2S+1) n), or None
+    cutoff     : truncbelow(eta) Schmidt-value cut (10^-svalue, src:1007), or 0
+    shard      : optional (rank, world, allreduce_fn) for the sector-parallel apply
+    """
+
+    def __init__(self, ops, mpo, bonds, tensors, chi_full=None, cutoff=0.0, krylovdim=30, lanczos_tol=1e-12,
+                 maxrestart=3, weighting="sqrtdim", jacobi_tol=1e-14, jacobi_max_sweeps=40, shard=None):
+        self.ops, self.mpo = ops, mpo
+        self.L = len(mpo)
+        self.chi_full, self.cutoff, self.weighting = chi_full, cutoff, weighting
+        self.krylovdim, self.lanczos_tol, self.maxrestart = krylovdim, lanczos_tol, maxrestart
+        self.jacobi_tol, self.jacobi_max_sweeps = jacobi_tol, jacobi_max_sweeps
+        self.shard = shard
+        self.bonds = [Bond(b) for b in bonds]
+        self.site_lay = [None] * self.L
+        self.site_buf = [None] * self.L
+        for i in range(self.L):
+            self._upload_site(i, tensors[i], "R")
+        self.Llay = [None] * (self.L + 1)
+        self.Lbuf = [None] * (self.L + 1)
+        self.Rlay = [None] * (self.L + 1)
+        self.Rbuf = [None] * (self.L + 1)
+        self.Llay[0] = EnvLayout.build("L", self.bonds[0], mpo[0].left)
+        self.Rlay[self.L] = EnvLayout.build("R", self.bonds[self.L], mpo[self.L - 1].right)
+        self.Lbuf[0] = ops.zeros_z(1)
+        self.Rbuf[self.L] = ops.zeros_z(1)
+        for i in range(self.L - 1, 0, -1):
+            self._right_env(i)
+        self.energy = None
+        self.stats = []
+        self.spectra = {}
+        self._plan_cache = {}
+
+    # ---- host <-> device site tensors -----------------------------------------------------------
+    def _upload_site(self, i, blocks, kind):
+        lay = SiteLayout.build(kind, self.bonds[i], self.bonds[i + 1])
+        flat = np.zeros(max(lay.size, 1), dtype=np.complex128)
+        for key, (off, m, n, ld) in lay.blocks.items():
+            blk = blocks.get(key)
+            if blk is None:
+                continue
+            assert blk.shape == (m, n), (key, blk.shape, (m, n))
+            # scatter column-major with leading dimension ld
+            idx = off + np.arange(m)[:, None] + ld * np.arange(n)[None, :]
+            flat[idx] = blk
+        self.site_lay[i] = lay
+        self.site_buf[i] = self.ops.to_device(flat)
+
+    def download_site(self, i):
+        lay = self.site_lay[i]
+        flat = self.ops.to_host(self.site_buf[i])
+        out = {}
+        for key, (off, m, n, ld) in lay.blocks.items():
+            idx = off + np.arange(m)[:, None] + ld * np.arange(n)[None, :]
+            out[key] = flat[idx].copy()
+        return out
+
+    def download_env(self, side, i):
+        lay = self.Llay[i] if side == "L" else self.Rlay[i]
+        flat = self.ops.to_host(self.Lbuf[i] if side == "L" else self.Rbuf[i])
+        return {key: flat[off:off + m * n].reshape(n, m).T.copy() for key, (off, m, n) in lay.blocks.items()}
+
+    # ---- environments -----------------------------------------------------------------------------
+    def _bufs(self, **kw):
+        table = [None] * 8
+        for k, v in kw.items():
+            table[{"x": BUF_X, "y": BUF_Y, "l": BUF_L, "r": BUF_R, "z": BUF_Z, "s1": BUF_S1, "s2": BUF_S2,
+                   "aux": BUF_AUX}[k]] = v
+        return table
+
+    def _left_env(self, i):
+        """GL on bond i+1 from GL on bond i and the left-layout tensor of site i"""
+        ops = self.ops
+        lay = self.site_lay[i]
+        assert lay.kind == "L"
+        Lnew = EnvLayout.build("L", self.bonds[i + 1], self.mpo[i].right)
+        t1, t2, zsize = pl.plan_left_env(self.Llay[i], lay, self.mpo[i], Lnew)
+        z = ops.empty_z(max(zsize, 1))
+        out = ops.empty_z(max(Lnew.size, 1))
+        ops.grouped_gemm(self._bufs(l=self.Lbuf[i], s1=self.site_buf[i], z=z), ops.upload_tasks(t1))
+        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], z=z, y=out), ops.upload_tasks(t2))
+        self.Llay[i + 1], self.Lbuf[i + 1] = Lnew, out
+        return t1.flops + t2.flops
+
+    def _right_env(self, i):
+        """GR on bond i from GR on bond i+1 and the right-layout tensor of site i"""
+        ops = self.ops
+        lay = self.site_lay[i]
+        assert lay.kind == "R"
+        Rnew = EnvLayout.build("R", self.bonds[i], self.mpo[i].left)
+        t1, t2, zsize = pl.plan_right_env(self.Rlay[i + 1], lay, self.mpo[i], Rnew)
+        z = ops.empty_z(max(zsize, 1))
+        out = ops.empty_z(max(Rnew.size, 1))
+        ops.grouped_gemm(self._bufs(r=self.Rbuf[i + 1], s1=self.site_buf[i], z=z), ops.upload_tasks(t1))
+        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], z=z, y=out), ops.upload_tasks(t2))
+        self.Rlay[i], self.Rbuf[i] = Rnew, out
+        return t1.flops + t2.flops
+
+    # ---- effective Hamiltonian --------------------------------------------------------------------
+    def _make_apply(self, i, tl):
+        ops = self.ops
+        tz, ty, zsize, nterms = pl.plan_apply(tl, self.Llay[i], self.Rlay[i + 2], self.mpo[i], self.mpo[i + 1])
+        if self.shard is not None:
+            rank, world, _ = self.shard
+            ty = _shard_tasks(ty, rank, world)
+        dz = ops.upload_tasks(tz) if tz is not None else None
+        dy = ops.upload_tasks(ty)
+        z = ops.empty_z(max(zsize, 1))
+        Lb, Rb = self.Lbuf[i], self.Rbuf[i + 2]
+
+        def apply(x, y):
+            if self.shard is not None:
+                ops.zero(y)
+            if dz is not None:
+                ops.grouped_gemm(self._bufs(x=x, l=Lb, z=z), dz)
+            ops.grouped_gemm(self._bufs(x=x, y=y, l=Lb, r=Rb, z=z), dy)
+            if self.shard is not None:
+                self.shard[2](y)
+        flops = ty.flops + (tz.flops if tz is not None else 0)
+        nbytes = 16 * (2 * tl.size + self.Llay[i].size + self.Rlay[i + 2].size)
+        return apply, flops, nbytes, ty.ntiles + (tz.ntiles if tz else 0), ty.nsegs + (tz.nsegs if tz else 0)
+
+    def _lanczos(self, apply, V, n, scal):
+        """lowest eigenpair; V: flat Krylov workspace with V[0:n] = normalised start vector.
+        Returns (eigenvalue, index of buffer row holding x, n_matvec, residual)."""
+        ops = self.ops
+        kd = self.krylovdim
+        nmv = 0
+        res, theta = None, None
+        for restart in range(self.maxrestart + 1):
+            alphas, betas = [], []
+            y = None
+            for j in range(kd):
+                vj = V[j * n:(j + 1) * n]
+                w = V[(j + 1) * n:(j + 2) * n]
+                apply(vj, w)
+                nmv += 1
+                c1 = scal[0:j + 1]
+                c2 = scal[kd + 1:kd + 2 + j]
+                ops.dots(V, n, j + 1, w, n, c1)
+                ops.axpys(w, V, n, j + 1, c1, -1.0, n)
+                ops.dots(V, n, j + 1, w, n, c2)
+                ops.axpys(w, V, n, j + 1, c2, -1.0, n)
+                nr = scal[2 * kd + 2:2 * kd + 3]
+                ops.dots(w, n, 1, w, n, nr)
+                h = ops.to_host(scal)
+                alpha = float(h[j].real + h[kd + 1 + j].real)
+                beta = float(np.sqrt(max(h[2 * kd + 2].real, 0.0)))
+                alphas.append(alpha)
+                theta, y = _tridiag_lowest(alphas, betas)
+                res = abs(beta * y[-1])
+                if res < self.lanczos_tol or beta < 1e-14 or j == kd - 1:
+                    break
+                betas.append(beta)
+                ops.scale_inv_sqrt(w, w, nr, n)
+            k = len(y)
+            # x = sum_i y_i V_i  -> store in row kd+1 (scratch row), then move to row 0
+            xrow = V[(kd + 1) * n:(kd + 2) * n]
+            ops.zero(xrow)
+            coef = ops.to_device(np.asarray(y, dtype=np.complex128))
+            ops.axpys(xrow, V, n, k, coef, 1.0, n)
+            nr = scal[2 * kd + 2:2 * kd + 3]
+            ops.dots(xrow, n, 1, xrow, n, nr)
+            ops.scale_inv_sqrt(V[0:n], xrow, nr, n)
+            if res < self.lanczos_tol or beta < 1e-14:
+                break
+        return theta, nmv, res
+
+    # ---- one bond ---------------------------------------------------------------------------------
+    def update_bond(self, i, direction, placement):
+        """optimise sites (i, i+1); placement 'right': A_i = U, centre S V^H on i+1 (+ left env);
+        'left': centre U S on i, B_{i+1} = V^H (+ right env)."""
+        t0 = time.perf_counter()
+        ops = self.ops
+        bl, br = self.bonds[i], self.bonds[i + 2]
+        tl = ThetaLayout.build(bl, br)
+        n = tl.size
+        kd = self.krylovdim
+        lay1, lay2 = self.site_lay[i], self.site_lay[i + 1]
+        mode = lay1.kind + lay2.kind
+        assert mode in ("RR", "LL", "LR"), mode
+        V = ops.empty_z((kd + 2) * n)
+        scal = ops.zeros_z(2 * kd + 4)
+        # theta -> V[0]
+        tth = pl.plan_theta(mode, lay1, lay2, tl)
+        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], s2=self.site_buf[i + 1], y=V[0:n]), ops.upload_tasks(tth))
+        nr = scal[2 * kd + 2:2 * kd + 3]
+        ops.dots(V[0:n], n, 1, V[0:n], n, nr)
+        ops.scale_inv_sqrt(V[0:n], V[0:n], nr, n)
+        apply, aflops, abytes, ntiles, nsegs = self._make_apply(i, tl)
+        t_plan = time.perf_counter() - t0
+        E, nmv, res = self._lanczos(apply, V, n, scal)
+        x = V[0:n]
+        # ---- SVD + truncation ----
+        sp = pl.plan_svd(tl)
+        nb = len(sp.mids)
+        G = ops.empty_z(max(sp.g_size, 1))
+        Vj = ops.empty_z(max(sp.v_size, 1))
+        S = ops.empty_f64(max(sp.s_size, 1))
+        info = ops.empty_i32(max(nb, 1))
+        ops.batched_copy(G, x, None, None, ops.to_device(sp.stage), nb, 1.0)
+        ops.jacobi_svd(G, Vj, S, ops.to_device(sp.desc), nb, sp.max_m, self.jacobi_max_sweeps, self.jacobi_tol, info)
+        s_host = ops.to_host(S)
+        info_h = ops.to_host(info)
+        if nb and int(info_h[:nb].min()) < 0:
+            raise RuntimeError("Jacobi SVD did not converge")
+        svals, order = {}, {}
+        for k, c in enumerate(sp.mids):
+            so, nn = int(sp.desc[k]["s_off"]), int(sp.desc[k]["n"])
+            s = s_host[so:so + nn]
+            p = np.argsort(-s, kind="stable")
+            order[c] = p
+            svals[c] = s[p]
+        keep, tw, nrm = pl.truncate(svals, self.chi_full, self.cutoff, self.weighting)
+        mid = Bond({c: k for c, k in keep.items() if k > 0})
+        layA = SiteLayout.build("L", bl, mid)
+        layB = SiteLayout.build("R", mid, br)
+        A_g, A_v, B_g, B_v, idx = pl.plan_finalize(tl, sp, order, keep, layA, layB, placement)
+        bufA = ops.zeros_z(max(layA.size, 1))
+        bufB = ops.zeros_z(max(layB.size, 1))
+        idx_d = ops.to_device(idx)
+        gA = 1.0 if placement == "right" else 1.0 / nrm
+        gB = 1.0 / nrm if placement == "right" else 1.0
+        if len(A_g):
+            ops.batched_copy(bufA, G, idx_d, S, ops.to_device(A_g), len(A_g), gA)
+        if len(A_v):
+            ops.batched_copy(bufA, Vj, idx_d, S, ops.to_device(A_v), len(A_v), gA)
+        if len(B_g):
+            ops.batched_copy(bufB, G, idx_d, S, ops.to_device(B_g), len(B_g), gB)
+        if len(B_v):
+            ops.batched_copy(bufB, Vj, idx_d, S, ops.to_device(B_v), len(B_v), gB)
+        self.bonds[i + 1] = mid
+        self.site_lay[i], self.site_buf[i] = layA, bufA
+        self.site_lay[i + 1], self.site_buf[i + 1] = layB, bufB
+        if placement == "right":
+            self._left_env(i)
+        else:
+            self._right_env(i + 1)
+        self.energy = E
+        self.spectra[i + 1] = {c: svals[c][:keep[c]] / nrm / np.sqrt(c[1] + 1) for c in svals if keep[c] > 0}
+        st = BondStats(bond=i + 1, direction=direction, energy=E, n_matvec=nmv, residual=res, trunc_weight=tw,
+                       chi_full=mid.dim_full, multiplets=mid.multiplets, theta_size=n, apply_flops=aflops,
+                       apply_bytes=abytes, svd_flops=sp.flops,
+                       jacobi_sweeps=int(info_h[:nb].max()) if nb else 0, n_tiles=ntiles, n_segs=nsegs,
+                       t_plan=t_plan, t_total=time.perf_counter() - t0)
+        self.stats.append(st)
+        return E
+
+    def sweep(self):
+        """one sweep in MPSKit's DMRG2 order: bonds 0..L-2 rightwards, L-3..0 leftwards."""
+        L = self.L
+        for i in range(L - 1):
+            self.update_bond(i, +1, "right" if i < L - 2 else "left")
+        for i in range(L - 3, -1, -1):
+            self.update_bond(i, -1, "left")
+        return self.energy
+
+    def bond_dims(self):
+        """`dim_state` analogue (src/HubbardFunctions.jl:1399-1405): TensorKit dim of each bond"""
+        return [b.dim_full for b in self.bonds]
+
+
+def _shard_tasks(tasks, rank, world):
+    """owner-computes split of the output tiles over ranks: tiles are sorted by work (LPT order),
+    dealing them round-robin balances MACs; every rank keeps the full segment table."""
+    import copy
+    t = copy.copy(tasks)
+    sel = np.arange(tasks.ntiles)[rank::world]
+    t.tiles = np.ascontiguousarray(tasks.tiles[sel]) if len(sel) else tasks.tiles[:1].copy()
+    t.ntiles = len(sel)
+    return t

@@ -1,0 +1,242 @@
+"""Host-side mirror of HubbardTN's model structs and Hamiltonian builder for the hot path.
+
+Keeps the reference's names and argument meaning (src/HubbardFunctions.jl:56-238):
+`OB_Sim(t, u, mu, [J], P, Q, svalue, bond_dim, period; kwargs...)` and
+`MB_Sim(t, u, J, [U13], P, Q, svalue, bond_dim; kwargs...)`.
+
+`hamiltonian(sim, L)` restates `hamiltonian(::OB_Sim)` (src:386-472) / `hamiltonian(::MB_Sim)`
+(src:811-910, hopping / chemical potential / direct terms) for an OPEN chain of L unit cells in
+reduced (SU(2) x U(1) x fZ2) form.  The reference only builds infinite-chain MPOs;
+the finite restatement keeps every term whose sites fit inside the chain.
+
+Reduced site operators (values = Wigner-Eckart reduced elements of the Jordan-Wigner matrices,
+matching the 1 / sqrt(2) entries of src:284-290):
+  sigma = 0: empty (N=0,S=0)   1: single (N=1,S=1/2)   2: double (N=2,S=0)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from math import sqrt
+
+import numpy as np
+
+SQ2 = sqrt(2.0)
+SITE_MULT = ((0, 0), (1, 1), (2, 0))      # (N, twoS) of the three site multiplets
+
+
+def _mat(entries):
+    m = np.zeros((3, 3))
+    for (o, i), v in entries.items():
+        m[o, i] = v
+    return m
+
+
+# name -> (k = doubled operator spin, dN, red[sigma_out, sigma_in])
+SITE_OPS = {
+    "id": (0, 0, _mat({(0, 0): 1, (1, 1): 1, (2, 2): 1})),
+    "F": (0, 0, _mat({(0, 0): 1, (1, 1): -1, (2, 2): 1})),          # fermion parity (JW string)
+    "n": (0, 0, _mat({(1, 1): 1, (2, 2): 2})),                      # Number(), src:312-327
+    "docc": (0, 0, _mat({(2, 2): 1})),                              # OSInteraction(), src:298-310
+    "cdag": (1, +1, _mat({(1, 0): 1, (2, 1): -SQ2})),               # c+ closing a term
+    "cdagF": (1, +1, _mat({(1, 0): 1, (2, 1): SQ2})),               # c+ opening a term (c+ F)
+    "c": (1, -1, _mat({(0, 1): SQ2, (1, 2): 1})),                   # c  closing a term
+    "Fc": (1, -1, _mat({(0, 1): SQ2, (1, 2): -1})),                 # c  opening a term (F c)
+}
+
+
+class Simulation:
+    pass
+
+
+@dataclass
+class OB_Sim(Simulation):
+    """One-band Hubbard model, fixed filling P/Q (src/HubbardFunctions.jl:76-93)."""
+    t: list
+    u: list
+    mu: float = 0.0
+    J: list = field(default_factory=lambda: [0.0])
+    P: int = 1
+    Q: int = 1
+    svalue: float = 2.0
+    bond_dim: int = 50
+    period: int = 0
+    kwargs: dict = field(default_factory=dict)
+
+    def __init__(self, t, u, mu=0.0, *args, **kwargs):
+        # two positional forms, distinguished by whether a J vector is passed (src:87-92)
+        args = list(args)
+        J = [0.0]
+        if args and isinstance(args[0], (list, tuple, np.ndarray)):
+            J = [float(x) for x in args.pop(0)]
+        defaults = [1, 1, 2.0, 50, 0]
+        vals = args + defaults[len(args):]
+        self.t = [float(x) for x in t]
+        self.u = [float(x) for x in u]
+        self.mu = float(mu)
+        self.J = J
+        self.P, self.Q = int(vals[0]), int(vals[1])
+        self.svalue, self.bond_dim, self.period = float(vals[2]), int(vals[3]), int(vals[4])
+        self.kwargs = dict(kwargs)
+
+    @property
+    def bands(self):
+        return 1
+
+
+@dataclass
+class MB_Sim(Simulation):
+    """Multi-band Hubbard model, fixed filling (src/HubbardFunctions.jl:117-134).
+    t, u, J: B x (nB) matrices, on-site | nearest-neighbour | ... blocks concatenated."""
+    t: np.ndarray
+    u: np.ndarray
+    J: np.ndarray
+    U13: np.ndarray
+    P: int = 1
+    Q: int = 1
+    svalue: float = 2.0
+    bond_dim: int = 50
+    kwargs: dict = field(default_factory=dict)
+
+    def __init__(self, t, u, J, *args, **kwargs):
+        args = list(args)
+        t = np.atleast_2d(np.asarray(t, dtype=float))
+        B = t.shape[0]
+        U13 = np.zeros((B, B))
+        if args and isinstance(args[0], np.ndarray):
+            U13 = np.asarray(args.pop(0), dtype=float)
+        defaults = [1, 1, 2.0, 50]
+        vals = args + defaults[len(args):]
+        self.t, self.u, self.J, self.U13 = t, np.atleast_2d(np.asarray(u, float)), np.atleast_2d(np.asarray(J, float)), U13
+        self.P, self.Q = int(vals[0]), int(vals[1])
+        self.svalue, self.bond_dim = float(vals[2]), int(vals[3])
+        self.kwargs = dict(kwargs)
+
+    @property
+    def bands(self):
+        return self.t.shape[0]
+
+
+# ----------------------------------------------------------------------------------------------
+# generic finite-chain MPO from a list of terms
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class MPOSite:
+    left: list        # [(dN, k)] per level of the left bond
+    right: list
+    entries: list     # [(wl, wr, opname, coef)]
+
+
+def _build_mpo(nsites, onsite, pairs):
+    """onsite: {site: [(opname, coef)]}; pairs: list of (i, j, kind, coef) with i < j (0-based),
+    kind in {'hop', 'nn'}: 'hop' = coef * sum_s (c+_{i s} c_{j s} + h.c.), 'nn' = coef * n_i n_j.
+    Finite-state-machine MPO: level 0 = nothing applied ('start'), last = complete ('final'),
+    one chain of levels per open two-site term (no compression, like `H += h`, src:439)."""
+    chans = {b: [] for b in range(nsites + 1)}      # bond b sits to the right of site b-1
+    for (i, j, kind, coef) in pairs:
+        if coef == 0.0:
+            continue
+        subs = (("hop+", (+1, 1)), ("hop-", (-1, 1))) if kind == "hop" else (("nn", (0, 0)),)
+        for sub, q in subs:
+            for b in range(i + 1, j + 1):
+                chans[b].append(((sub, i, j), q))
+    sites = []
+    for s in range(nsites):
+        def levels(b):
+            if b == 0:
+                return [("start",)], [(0, 0)]
+            if b == nsites:
+                return [("final",)], [(0, 0)]
+            names = [("start",)] + [c[0] for c in chans[b]] + [("final",)]
+            qn = [(0, 0)] + [c[1] for c in chans[b]] + [(0, 0)]
+            return names, qn
+        nl, ql = levels(s)
+        nr, qr = levels(s + 1)
+        il = {n: k for k, n in enumerate(nl)}
+        ir = {n: k for k, n in enumerate(nr)}
+        ent = []
+        if ("start",) in il and ("start",) in ir:
+            ent.append((il[("start",)], ir[("start",)], "id", 1.0))
+        if ("final",) in il and ("final",) in ir:
+            ent.append((il[("final",)], ir[("final",)], "id", 1.0))
+        for (op, coef) in onsite.get(s, []):
+            if coef != 0.0:
+                ent.append((il[("start",)], ir[("final",)], op, coef))
+        for name in nr:
+            if name[0] in ("start", "final"):
+                continue
+            sub, i, j = name
+            if i == s:
+                ent.append((il[("start",)], ir[name], {"hop+": "cdagF", "hop-": "Fc", "nn": "n"}[sub], 1.0))
+            else:
+                ent.append((il[name], ir[name], "id" if sub == "nn" else "F", 1.0))
+        coefs = {(i, j, kind): c for (i, j, kind, c) in pairs}
+        for name in nl:
+            if name[0] in ("start", "final"):
+                continue
+            sub, i, j = name
+            if j == s:
+                if sub == "hop+":
+                    ent.append((il[name], ir[("final",)], "c", coefs[(i, j, "hop")] * SQ2))
+                elif sub == "hop-":
+                    ent.append((il[name], ir[("final",)], "cdag", -coefs[(i, j, "hop")] * SQ2))
+                else:
+                    ent.append((il[name], ir[("final",)], "n", coefs[(i, j, "nn")]))
+        sites.append(MPOSite(ql, qr, ent))
+    return sites
+
+
+def hamiltonian(sim: Simulation, L: int):
+    """Reduced open-chain MPO over L unit cells (L*B sites).  Returns list[MPOSite]."""
+    if isinstance(sim, OB_Sim):
+        if sim.period != 0:
+            raise NotImplementedError("helix (period != 0) is outside the hot-path scope (SURVEY 8f)")
+        if any(x != 0.0 for x in sim.J) or sim.kwargs.get("U13", [0.0]) != [0.0]:
+            raise NotImplementedError("exchange / U13 terms are a 'next' row (SURVEY 8f.2)")
+        onsite = {s: [("docc", sim.u[0]), ("n", -sim.mu)] for s in range(L)}          # src:424
+        pairs = []
+        for r, tr in enumerate(sim.t, start=1):                                       # src:437-440
+            for i in range(L - r):
+                pairs.append((i, i + r, "hop", -tr))
+        for r in range(1, len(sim.u)):                                                # src:441-444
+            for i in range(L - r):
+                pairs.append((i, i + r, "nn", sim.u[r]))
+        return _build_mpo(L, onsite, pairs)
+    if isinstance(sim, MB_Sim):
+        B = sim.bands
+        if np.any(sim.J != 0.0) or np.any(sim.U13 != 0.0):
+            raise NotImplementedError("multi-band exchange / U13 terms are a 'next' row (SURVEY 8f.2)")
+        t, u = sim.t, sim.u
+        n = L * B
+        site = lambda band, cell: band + cell * B                                     # InfiniteStrip(B, T*B), src:491
+        onsite = {}
+        for cell in range(L):
+            for b in range(B):
+                onsite[site(b, cell)] = [("docc", u[b, b]), ("n", -t[b, b])]          # src:853-864, 872-876
+        acc = {}
+
+        def add(i, j, kind, c):
+            if i > j:
+                i, j = j, i
+            acc[(i, j, kind)] = acc.get((i, j, kind), 0.0) + c
+        for cell in range(L):
+            for bi in range(B):
+                for bf in range(B):
+                    if bi < bf:
+                        # OS_Hopping sums -t[bi,bf] cdc{bf,bi} over ordered pairs = -t (cdc + cdc')
+                        add(site(bi, cell), site(bf, cell), "hop", -0.5 * (t[bi, bf] + t[bf, bi]))  # src:498
+                        add(site(bi, cell), site(bf, cell), "nn", 0.5 * (u[bi, bf] + u[bf, bi]))    # src:548-561
+        for r in range(1, t.shape[1] // B):
+            M = t[:, B * r:B * (r + 1)]
+            for cell in range(L - r):
+                for bi in range(B):
+                    for bf in range(B):
+                        add(site(bi, cell), site(bf, cell + r), "hop", -M[bi, bf])                  # src:515
+        for r in range(1, u.shape[1] // B):
+            M = u[:, B * r:B * (r + 1)]
+            for cell in range(L - r):
+                for bi in range(B):
+                    for bf in range(B):
+                        add(site(bi, cell), site(bf, cell + r), "nn", M[bi, bf])                    # src:664
+        pairs = [(i, j, kind, c) for (i, j, kind), c in sorted(acc.items()) if c != 0.0]
+        return _build_mpo(n, onsite, pairs)
+    raise TypeError(f"unsupported simulation type {type(sim)}")

@@ -1,0 +1,41 @@
+"""Initial matrix-product states for the finite-chain engine.
+
+`random_mps` mirrors `initialize_mps` (src/HubbardFunctions.jl:917-959): virtual spaces are the
+intersection of what can be fused from the left and from the right, capped PER SECTOR at
+`max_dimension` multiplets (src:931-938), tensors random; here for an open chain with a target
+total sector and returned in right-canonical form (Euclidean "tilde" normalisation).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .planner import full_bonds, fuse
+
+
+def random_mps(nsites, target, max_dimension, seed=1234):
+    """returns (bonds: list[dict], tensors: list[dict (l,s,r) -> ndarray])"""
+    rng = np.random.default_rng(seed)
+    bonds = [{sec: min(n, max_dimension) for sec, n in b.dims.items()} for b in full_bonds(nsites, target)]
+    tensors = [None] * nsites
+    for i in range(nsites - 1, -1, -1):
+        bl, br = bonds[i], bonds[i + 1]
+        T = {}
+        for c in sorted(bl):
+            cols = [(s, b) for s in range(3) for b in fuse(c, s) if b in br]
+            ncols = sum(br[b] for (_, b) in cols)
+            if ncols == 0:
+                del bl[c]
+                continue
+            nc = min(bl[c], ncols)
+            bl[c] = nc
+            M = rng.standard_normal((nc, ncols)) + 1j * rng.standard_normal((nc, ncols))
+            q, _ = np.linalg.qr(M.conj().T)
+            M = q.conj().T
+            off = 0
+            for (s, b) in cols:
+                T[(c, s, b)] = np.ascontiguousarray(M[:, off:off + br[b]])
+                off += br[b]
+        tensors[i] = T
+    for i in range(nsites):
+        tensors[i] = {k: v for k, v in tensors[i].items() if k[0] in bonds[i] and k[2] in bonds[i + 1]}
+    return bonds, tensors

@@ -1,0 +1,654 @@
+"""Host planner: turns sector tables + a reduced MPO into the task lists the HIP kernels execute.
+
+This is the MI355X-first replacement for what TensorKit does with fusion trees and tree
+transformers around every contraction: instead of permuting
+tensors between matricisations at run time, every contraction on the two-site DMRG path is
+compiled ONCE per bond geometry into a list of (output tile, segment) records for the grouped
+GEMM kernel; recoupling coefficients (closed-form 9j, hubbardtn_amd/wigner.py) become the
+segments' alpha.
+
+Layouts (all column-major, complex128, Euclidean "tilde" normalisation -- DESIGN.md):
+  two-site tensor  : per mid sector c one dense matrix M_c[(a,s1) rows ; (s2,b) cols]
+  left site tensor : per right sector c  matrix [(a,s) rows ; n_c]           (= U of the SVD)
+  right site tensor: per left sector c   matrix [n_c ; (s,b) cols]           (= V^H of the SVD)
+  left env   L     : blocks (a', w, a)  -> [n_a', n_a]; level 0 ('start') implicit identity
+  right env  Rt    : blocks (b, w, b')  -> [n_b, n_b'] (stored transposed); last level implicit identity
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from functools import lru_cache
+from math import sqrt
+
+import numpy as np
+
+from .abi import COPY_DT, OP_C, OP_N, OP_T, SEG_COPY, SEG_DT, SEG_GEMM, SVD_DT, TILE_DT, HTN_TILE
+from .models import SITE_MULT, SITE_OPS
+from .wigner import triangle, wigner9j
+
+# buffer-table slots shared by all plans
+BUF_X, BUF_Y, BUF_L, BUF_R, BUF_Z, BUF_S1, BUF_S2, BUF_AUX = range(8)
+
+
+# ----------------------------------------------------------------------------------------------
+# recoupling coefficients (validated against oracle/su2.py in tests/test_wigner.py)
+# ----------------------------------------------------------------------------------------------
+@lru_cache(maxsize=None)
+def coef_left(jbp, k, jb, jsp, js, kop, jap, kp, ja):
+    """L'[a',w',a] += coef * A[b',s',a']^+ L[b',w,b] W[w,s',s,w'] A[b,s,a]"""
+    return sqrt((jbp + 1) * (jsp + 1) * (ja + 1) * (kp + 1)) * wigner9j(jb, k, jbp, js, kop, jsp, ja, kp, jap)
+
+
+@lru_cache(maxsize=None)
+def coef_right(jcp, k, jc, jsp, js, kop, jbp, kp, jb):
+    """R[c',w,c] += coef * conj(B[c',s',b']) W[w,s',s,w'] R[b',w',b] B[c,s,b]"""
+    return (wigner9j(jc, k, jcp, js, kop, jsp, jb, kp, jbp) * sqrt((kp + 1) * (jsp + 1))
+            * (jc + 1) * (jbp + 1) / sqrt((jb + 1) * (jcp + 1)))
+
+
+@lru_cache(maxsize=None)
+def coef_apply(ja, jap, k, js1, js1p, kop1, km, jc, jcp, js2, js2p, kop2, kp, jb, jbp):
+    """y[a',s1',c',s2',b'] += coef * L[a',w,a] theta[a,s1,c,s2,b] R[b',w',b]^T"""
+    return (coef_left(jap, k, ja, js1p, js1, kop1, jcp, km, jc)
+            * coef_left(jcp, km, jc, js2p, js2, kop2, jbp, kp, jb) * (jbp + 1) / (jb + 1))
+
+
+# ----------------------------------------------------------------------------------------------
+# sectors, bonds, layouts
+# ----------------------------------------------------------------------------------------------
+def fuse(sec, s):
+    N, j = sec
+    Ns, js = SITE_MULT[s]
+    return [(N + Ns, jj) for jj in range(abs(j - js), j + js + 1, 2)]
+
+
+def split(sec, s):
+    N, j = sec
+    Ns, js = SITE_MULT[s]
+    if N < Ns:
+        return []
+    return [(N - Ns, jj) for jj in range(abs(j - js), j + js + 1, 2)]
+
+
+class Bond:
+    """ordered sector table of one virtual bond: sector (N, twoS) -> multiplet count"""
+
+    def __init__(self, dims: dict):
+        items = sorted((k, int(v)) for k, v in dims.items() if v > 0)
+        self.secs = [k for k, _ in items]
+        self.dims = {k: v for k, v in items}
+
+    def __contains__(self, sec):
+        return sec in self.dims
+
+    def __getitem__(self, sec):
+        return self.dims[sec]
+
+    def __iter__(self):
+        return iter(self.secs)
+
+    def __eq__(self, other):
+        return isinstance(other, Bond) and self.dims == other.dims
+
+    def key(self):
+        return tuple(sorted(self.dims.items()))
+
+    @property
+    def dim_full(self):
+        """TensorKit `dim` (SU(2)-expanded), the unit `dim_state` prints (src:1399-1405)"""
+        return sum((j + 1) * n for (N, j), n in self.dims.items())
+
+    @property
+    def multiplets(self):
+        return sum(self.dims.values())
+
+
+def full_bonds(nsites, target):
+    """exact (untruncated) bond tables of an open chain with total sector `target`"""
+    left = [{(0, 0): 1}]
+    for _ in range(nsites):
+        nxt = {}
+        for sec, n in left[-1].items():
+            for s in range(3):
+                for c in fuse(sec, s):
+                    nxt[c] = nxt.get(c, 0) + n
+        left.append(nxt)
+    right = [{target: 1}]
+    for _ in range(nsites):
+        prv = {}
+        for sec, n in right[-1].items():
+            for s in range(3):
+                for c in split(sec, s):
+                    prv[c] = prv.get(c, 0) + n
+        right.append(prv)
+    right = right[::-1]
+    return [Bond({sec: min(left[i][sec], right[i][sec]) for sec in left[i] if sec in right[i]})
+            for i in range(nsites + 1)]
+
+
+@dataclass
+class SiteLayout:
+    """layout of a one-site tensor between bond_l and bond_r; kind 'L' groups by the right
+    sector (matrix rows = (l, s) groups), kind 'R' groups by the left sector (cols = (s, r))."""
+    kind: str
+    bond_l: Bond
+    bond_r: Bond
+    blocks: dict = field(default_factory=dict)     # (l, s, r) -> (off, m, n, ld)
+    mats: dict = field(default_factory=dict)       # group sector -> (off, rows, cols, groups)
+    size: int = 0
+
+    @staticmethod
+    def build(kind, bond_l, bond_r):
+        lay = SiteLayout(kind, bond_l, bond_r)
+        off = 0
+        if kind == "L":
+            for r in bond_r:
+                groups = [(l, s) for s in range(3) for l in split(r, s) if l in bond_l]
+                groups.sort()
+                rows = sum(bond_l[l] for (l, s) in groups)
+                if rows == 0:
+                    continue
+                n = bond_r[r]
+                ro = 0
+                for (l, s) in groups:
+                    lay.blocks[(l, s, r)] = (off + ro, bond_l[l], n, rows)
+                    ro += bond_l[l]
+                lay.mats[r] = (off, rows, n, groups)
+                off += rows * n
+        else:
+            for l in bond_l:
+                groups = [(s, r) for s in range(3) for r in fuse(l, s) if r in bond_r]
+                groups.sort()
+                cols = sum(bond_r[r] for (s, r) in groups)
+                if cols == 0:
+                    continue
+                m = bond_l[l]
+                co = 0
+                for (s, r) in groups:
+                    lay.blocks[(l, s, r)] = (off + co * m, m, bond_r[r], m)
+                    co += bond_r[r]
+                lay.mats[l] = (off, m, cols, groups)
+                off += m * cols
+        lay.size = off
+        return lay
+
+
+@dataclass
+class ThetaLayout:
+    """coupled-sector layout of the two-site tensor between bond_l and bond_r"""
+    bond_l: Bond
+    bond_r: Bond
+    mids: list = field(default_factory=list)
+    mats: dict = field(default_factory=dict)      # c -> (off, rows, cols, rowgroups, colgroups, roffs, coffs)
+    blocks: dict = field(default_factory=dict)    # (a,s1,c,s2,b) -> (off, m, n, ld)
+    size: int = 0
+
+    @staticmethod
+    def build(bond_l, bond_r):
+        lay = ThetaLayout(bond_l, bond_r)
+        rg, cg = {}, {}
+        for a in bond_l:
+            for s1 in range(3):
+                for c in fuse(a, s1):
+                    rg.setdefault(c, []).append((a, s1))
+        for b in bond_r:
+            for s2 in range(3):
+                for c in split(b, s2):
+                    cg.setdefault(c, []).append((s2, b))
+        off = 0
+        for c in sorted(set(rg) & set(cg)):
+            rows_g = sorted(rg[c])
+            cols_g = sorted(cg[c])
+            roffs = np.cumsum([0] + [bond_l[a] for (a, _) in rows_g])
+            coffs = np.cumsum([0] + [bond_r[b] for (_, b) in cols_g])
+            rows, cols = int(roffs[-1]), int(coffs[-1])
+            lay.mids.append(c)
+            lay.mats[c] = (off, rows, cols, rows_g, cols_g, roffs, coffs)
+            for i, (a, s1) in enumerate(rows_g):
+                for j, (s2, b) in enumerate(cols_g):
+                    lay.blocks[(a, s1, c, s2, b)] = (off + int(roffs[i]) + int(coffs[j]) * rows,
+                                                     bond_l[a], bond_r[b], rows)
+            off += rows * cols
+        lay.size = off
+        return lay
+
+
+@dataclass
+class EnvLayout:
+    """blocks of a left (side='L': key (bra, w, ket) -> [n_bra, n_ket]) or right
+    (side='R': key (ket, w, bra) -> [n_ket, n_bra], i.e. stored transposed) environment."""
+    side: str
+    bond: Bond
+    levels: list                                  # [(dN, k)] of the MPO bond
+    blocks: dict = field(default_factory=dict)    # key -> (off, m, n)
+    by_ket: dict = field(default_factory=dict)    # (w, ket) -> [bra]
+    size: int = 0
+
+    @staticmethod
+    def build(side, bond, levels):
+        lay = EnvLayout(side, bond, list(levels))
+        ident = 0 if side == "L" else len(levels) - 1
+        off = 0
+        for w, (dN, k) in enumerate(levels):
+            if w == ident:
+                continue
+            for ket in bond:
+                for bra in bond:
+                    if bra[0] != ket[0] + dN or not triangle(ket[1], k, bra[1]):
+                        continue
+                    if side == "L":
+                        lay.blocks[(bra, w, ket)] = (off, bond[bra], bond[ket])
+                    else:
+                        lay.blocks[(ket, w, bra)] = (off, bond[ket], bond[bra])
+                    lay.by_ket.setdefault((w, ket), []).append(bra)
+                    off += bond[bra] * bond[ket]
+        lay.size = off
+        lay.ident = ident
+        return lay
+
+
+# ----------------------------------------------------------------------------------------------
+# task-list assembly
+# ----------------------------------------------------------------------------------------------
+class TaskList:
+    """collects output blocks with their segments and emits the htn_tile / htn_seg arrays"""
+
+    def __init__(self):
+        self.blocks = {}     # key -> dict(buf, off, m, n, ld, segs=[...])
+
+    def block(self, key, buf, off, m, n, ld):
+        b = self.blocks.get(key)
+        if b is None:
+            b = dict(buf=buf, off=off, m=m, n=n, ld=ld, segs=[])
+            self.blocks[key] = b
+        return b
+
+    def gemm(self, key, buf_a, a_off, lda, op_a, buf_b, b_off, ldb, op_b, k, alpha):
+        self.blocks[key]["segs"].append((SEG_GEMM, buf_a, a_off, lda, op_a, buf_b, b_off, ldb, op_b, k, alpha))
+
+    def copy(self, key, buf_b, b_off, ldb, alpha):
+        self.blocks[key]["segs"].append((SEG_COPY, 0, 0, 1, OP_N, buf_b, b_off, ldb, OP_N, 0, alpha))
+
+    def finalize(self):
+        nseg = sum(len(b["segs"]) for b in self.blocks.values())
+        segs = np.zeros(max(nseg, 1), dtype=SEG_DT)
+        tiles = []
+        pos = 0
+        flops = 0
+        for b in self.blocks.values():
+            # merge segments with identical operands (sums alpha)
+            merged = {}
+            for sg in b["segs"]:
+                merged[sg[:10]] = merged.get(sg[:10], 0.0) + sg[10]
+            seglist = [(k_, a_) for k_, a_ in merged.items() if a_ != 0.0]
+            start = pos
+            ksum = 0
+            for (typ, buf_a, a_off, lda, op_a, buf_b, b_off, ldb, op_b, k), alpha in seglist:
+                s = segs[pos]
+                s["type"], s["buf_a"], s["a_off"], s["lda"], s["op_a"] = typ, buf_a, a_off, lda, op_a
+                s["buf_b"], s["b_off"], s["ldb"], s["op_b"], s["k"] = buf_b, b_off, ldb, op_b, k
+                s["alpha_re"], s["alpha_im"] = alpha.real, alpha.imag
+                pos += 1
+                ksum += k if typ == SEG_GEMM else 0
+            cnt = pos - start
+            flops += 8 * b["m"] * b["n"] * ksum
+            for r0 in range(0, b["m"], HTN_TILE):
+                for c0 in range(0, b["n"], HTN_TILE):
+                    tm, tn = min(HTN_TILE, b["m"] - r0), min(HTN_TILE, b["n"] - c0)
+                    tiles.append((tm * tn * (ksum + 1), b["off"], b["buf"], b["ld"], tm, tn, r0, c0, start, cnt))
+        tiles.sort(key=lambda t: -t[0])      # longest first: hardware dispatch order = LPT schedule
+        tarr = np.zeros(max(len(tiles), 1), dtype=TILE_DT)
+        for i, t in enumerate(tiles):
+            (_, tarr[i]["c_off"], tarr[i]["buf_c"], tarr[i]["ldc"], tarr[i]["m"], tarr[i]["n"],
+             tarr[i]["row0"], tarr[i]["col0"], tarr[i]["seg_begin"], tarr[i]["seg_count"]) = t
+        return Tasks(tarr, len(tiles), segs[:max(pos, 1)], pos, flops)
+
+
+@dataclass
+class Tasks:
+    tiles: np.ndarray
+    ntiles: int
+    segs: np.ndarray
+    nsegs: int
+    flops: int            # algorithmic complex128 flops (8 per MAC) of the GEMM segments
+
+
+# ----------------------------------------------------------------------------------------------
+# plans
+# ----------------------------------------------------------------------------------------------
+def _w_by_left(W):
+    out = {}
+    for e in W.entries:
+        out.setdefault(e[0], []).append(e)
+    return out
+
+
+def plan_apply(tl: ThetaLayout, Ll: EnvLayout, Rl: EnvLayout, W1, W2):
+    """y = H_eff x  (SURVEY 8a a7).  Returns (stageZ Tasks | None, stageY Tasks, z_size, nterms)."""
+    nfin = len(W2.right) - 1
+    w2 = _w_by_left(W2)
+    ty, tz = TaskList(), TaskList()
+    for key, (off, m, n, ld) in tl.blocks.items():
+        ty.block(key, BUF_Y, off, m, n, ld)
+    zoff = 0
+    zblocks = {}
+    nterms = 0
+    for beta, (xoff, xm, xn, xld) in tl.blocks.items():
+        a, s1, c, s2, b = beta
+        js1, js2 = SITE_MULT[s1][1], SITE_MULT[s2][1]
+        for (w, wm, n1, c1) in W1.entries:
+            k1, dN1, red1 = SITE_OPS[n1]
+            kw, kmid = W1.left[w][1], W1.right[wm][1]
+            aps = [a] if w == 0 else Ll.by_ket.get((w, a), [])
+            if not aps:
+                continue
+            for s1p in range(3):
+                r1 = red1[s1p, s1]
+                if r1 == 0.0:
+                    continue
+                for (_, wp, n2, c2) in w2.get(wm, []):
+                    k2, dN2, red2 = SITE_OPS[n2]
+                    kwp = W2.right[wp][1]
+                    bps = [b] if wp == nfin else Rl.by_ket.get((wp, b), [])
+                    if not bps:
+                        continue
+                    for s2p in range(3):
+                        r2 = red2[s2p, s2]
+                        if r2 == 0.0:
+                            continue
+                        for ap in aps:
+                            for cp in fuse(ap, s1p):
+                                for bp in bps:
+                                    betap = (ap, s1p, cp, s2p, bp)
+                                    if betap not in tl.blocks:
+                                        continue
+                                    cf = coef_apply(a[1], ap[1], kw, js1, SITE_MULT[s1p][1], k1, kmid, c[1],
+                                                    cp[1], js2, SITE_MULT[s2p][1], k2, kwp, b[1], bp[1])
+                                    alpha = cf * r1 * r2 * c1 * c2
+                                    if alpha == 0.0:
+                                        continue
+                                    nterms += 1
+                                    hasL, hasR = (w != 0), (wp != nfin)
+                                    if not hasL and not hasR:
+                                        ty.copy(betap, BUF_X, xoff, xld, alpha)
+                                    elif hasL and not hasR:
+                                        lo, lm, ln = Ll.blocks[(ap, w, a)]
+                                        ty.gemm(betap, BUF_L, lo, lm, OP_N, BUF_X, xoff, xld, OP_N, ln, alpha)
+                                    elif hasR and not hasL:
+                                        ro, rm, rn = Rl.blocks[(b, wp, bp)]
+                                        ty.gemm(betap, BUF_X, xoff, xld, OP_N, BUF_R, ro, rm, OP_N, rm, alpha)
+                                    else:
+                                        lo, lm, ln = Ll.blocks[(ap, w, a)]
+                                        ro, rm, rn = Rl.blocks[(b, wp, bp)]
+                                        zk = (betap, wp, b)
+                                        if zk not in zblocks:
+                                            zblocks[zk] = zoff
+                                            tz.block(zk, BUF_Z, zoff, lm, xn, lm)
+                                            ty.gemm(betap, BUF_Z, zoff, lm, OP_N, BUF_R, ro, rm, OP_N, rm, 1.0)
+                                            zoff += lm * xn
+                                        tz.gemm(zk, BUF_L, lo, lm, OP_N, BUF_X, xoff, xld, OP_N, ln, alpha)
+    tasks_z = tz.finalize() if zblocks else None
+    return tasks_z, ty.finalize(), zoff, nterms
+
+
+def plan_theta(mode, lay1: SiteLayout, lay2: SiteLayout, tl: ThetaLayout):
+    """theta = T1 . T2 on sites (i, i+1).  mode 'RR': both right layout (centre on i);
+    'LL': both left layout (centre on i+1); 'LR': left layout x right layout.
+    buffers: BUF_S1 = site i, BUF_S2 = site i+1, output BUF_Y."""
+    t = TaskList()
+    for c in tl.mids:
+        off, rows, cols, rows_g, cols_g, roffs, coffs = tl.mats[c]
+        if mode == "LR":
+            t.block(("m", c), BUF_Y, off, rows, cols, rows)
+            if c in lay1.mats and c in lay2.mats:
+                o1, r1, n1, g1 = lay1.mats[c]
+                o2, m2, c2, g2 = lay2.mats[c]
+                assert g1 == rows_g and g2 == cols_g and r1 == rows and c2 == cols
+                t.gemm(("m", c), BUF_S1, o1, r1, OP_N, BUF_S2, o2, m2, OP_N, n1, 1.0)
+        elif mode == "RR":
+            has2 = c in lay2.mats
+            if has2:
+                o2, m2, c2, g2 = lay2.mats[c]
+                assert g2 == cols_g and c2 == cols
+            for i, (a, s1) in enumerate(rows_g):
+                key = ("r", a, s1, c)
+                t.block(key, BUF_Y, off + int(roffs[i]), tl.bond_l[a], cols, rows)
+                blk = lay1.blocks.get((a, s1, c))
+                if blk is not None and has2:
+                    bo, bm, bn, bld = blk
+                    t.gemm(key, BUF_S1, bo, bld, OP_N, BUF_S2, o2, m2, OP_N, bn, 1.0)
+        elif mode == "LL":
+            has1 = c in lay1.mats
+            if has1:
+                o1, r1, n1, g1 = lay1.mats[c]
+                assert g1 == rows_g and r1 == rows
+            for j, (s2, b) in enumerate(cols_g):
+                key = ("c", c, s2, b)
+                t.block(key, BUF_Y, off + int(coffs[j]) * rows, rows, tl.bond_r[b], rows)
+                blk = lay2.blocks.get((c, s2, b))
+                if blk is not None and has1:
+                    bo, bm, bn, bld = blk
+                    t.gemm(key, BUF_S1, o1, r1, OP_N, BUF_S2, bo, bld, OP_N, bm, 1.0)
+        else:
+            raise ValueError(mode)
+    return t.finalize()
+
+
+def plan_left_env(Ll: EnvLayout, lay: SiteLayout, W, Lnew: EnvLayout):
+    """GL[i+1] from GL[i], left-layout site tensor (BUF_S1), MPO site W (a10).
+    stage 1 -> BUF_Z (Y panels), stage 2 -> BUF_Y (new env).  Returns (t1, t2, z_size)."""
+    assert lay.kind == "L"
+    t1, t2 = TaskList(), TaskList()
+    zoff = 0
+    ypanel = {}
+    # stage-2 outputs
+    for (cp, wp, c), (off, m, n) in Lnew.blocks.items():
+        if cp not in lay.mats or c not in lay.mats:
+            t2.block((cp, wp, c), BUF_Y, off, m, n, m)      # structurally zero block
+            continue
+        o_cp, rows_cp, n_cp, g_cp = lay.mats[cp]
+        t2.block((cp, wp, c), BUF_Y, off, m, n, m)
+        ypanel[(cp, wp, c)] = zoff
+        t2.gemm((cp, wp, c), BUF_S1, o_cp, rows_cp, OP_C, BUF_Z, zoff, rows_cp, OP_N, rows_cp, 1.0)
+        ro = 0
+        for (ap, sp) in g_cp:
+            t1.block((cp, wp, c, ap, sp), BUF_Z, zoff + ro, lay.bond_l[ap], n, rows_cp)
+            ro += lay.bond_l[ap]
+        zoff += rows_cp * n
+    for (wl, wr, name, coef) in W.entries:
+        if wr == 0 and len(W.right) > 1:
+            continue                                  # 'start' level stays the implicit identity
+        kop, dN, red = SITE_OPS[name]
+        kl, kr = W.left[wl][1], W.right[wr][1]
+        for (a, s, c), (aoff, am, an, ald) in lay.blocks.items():
+            for sp in range(3):
+                r = red[sp, s]
+                if r == 0.0:
+                    continue
+                aps = [a] if wl == 0 else Ll.by_ket.get((wl, a), [])
+                for ap in aps:
+                    for cp in fuse(ap, sp):
+                        if (cp, wr, c) not in ypanel or (ap, sp, cp) not in lay.blocks:
+                            continue
+                        cf = coef_left(ap[1], kl, a[1], SITE_MULT[sp][1], SITE_MULT[s][1], kop, cp[1], kr, c[1])
+                        alpha = cf * r * coef
+                        if alpha == 0.0:
+                            continue
+                        key = (cp, wr, c, ap, sp)
+                        if wl == 0:
+                            t1.copy(key, BUF_S1, aoff, ald, alpha)
+                        else:
+                            lo, lm, ln = Ll.blocks[(ap, wl, a)]
+                            t1.gemm(key, BUF_L, lo, lm, OP_N, BUF_S1, aoff, ald, OP_N, ln, alpha)
+    return t1.finalize(), t2.finalize(), zoff
+
+
+def plan_right_env(Rl: EnvLayout, lay: SiteLayout, W, Rnew: EnvLayout):
+    """GR[i] (stored transposed: block (c, w, c') = [n_c, n_c']) from GR[i+1], right-layout
+    site tensor (BUF_S1) and MPO site W.  Returns (t1, t2, z_size)."""
+    assert lay.kind == "R"
+    t1, t2 = TaskList(), TaskList()
+    nfin_r, nfin_l = len(W.right) - 1, len(W.left) - 1
+    zoff = 0
+    ypanel = {}
+    for (c, w, cp), (off, m, n) in Rnew.blocks.items():
+        t2.block((c, w, cp), BUF_Y, off, m, n, m)
+        if cp not in lay.mats or c not in lay.mats:
+            continue
+        o_cp, m_cp, cols_cp, g_cp = lay.mats[cp]
+        ypanel[(c, w, cp)] = zoff
+        # Rt[c, w, c'] (n_c x n_c') = Y (n_c x cols') . B_{c'}^H (cols' x n_c')
+        t2.gemm((c, w, cp), BUF_Z, zoff, m, OP_N, BUF_S1, o_cp, m_cp, OP_C, cols_cp, 1.0)
+        co = 0
+        for (sp, bp) in g_cp:
+            t1.block((c, w, cp, sp, bp), BUF_Z, zoff + co * m, m, lay.bond_r[bp], m)
+            co += lay.bond_r[bp]
+        zoff += m * cols_cp
+    for (wl, wr, name, coef) in W.entries:
+        if wl == nfin_l and len(W.left) > 1:
+            continue                                  # 'final' level stays the implicit identity
+        kop, dN, red = SITE_OPS[name]
+        kl, kr = W.left[wl][1], W.right[wr][1]
+        for (c, s, b), (boff, bm, bn, bld) in lay.blocks.items():
+            for sp in range(3):
+                r = red[sp, s]
+                if r == 0.0:
+                    continue
+                bps = [b] if wr == nfin_r else Rl.by_ket.get((wr, b), [])
+                for bp in bps:
+                    for cp in split(bp, sp):
+                        if (c, wl, cp) not in ypanel or (cp, sp, bp) not in lay.blocks:
+                            continue
+                        cf = coef_right(cp[1], kl, c[1], SITE_MULT[sp][1], SITE_MULT[s][1], kop, bp[1], kr, b[1])
+                        alpha = cf * r * coef
+                        if alpha == 0.0:
+                            continue
+                        key = (c, wl, cp, sp, bp)
+                        if wr == nfin_r:
+                            t1.copy(key, BUF_S1, boff, bld, alpha)
+                        else:
+                            ro, rm, rn = Rl.blocks[(b, wr, bp)]
+                            t1.gemm(key, BUF_S1, boff, bld, OP_N, BUF_R, ro, rm, OP_N, rm, alpha)
+    return t1.finalize(), t2.finalize(), zoff
+
+
+# ----------------------------------------------------------------------------------------------
+# SVD staging / truncation
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class SvdPlan:
+    desc: np.ndarray            # SVD_DT per mid sector
+    stage: np.ndarray           # COPY_DT items copying M_c or M_c^H into the Jacobi workspace
+    mids: list
+    transposed: list            # per block: True if G = M^H
+    g_size: int
+    v_size: int
+    s_size: int
+    max_m: int
+    flops: int                  # LAPACK-equivalent flops, SURVEY 8(d)
+
+
+def plan_svd(tl: ThetaLayout):
+    n = len(tl.mids)
+    desc = np.zeros(max(n, 1), dtype=SVD_DT)
+    stage = np.zeros(max(n, 1), dtype=COPY_DT)
+    go = vo = so = 0
+    transposed = []
+    max_m = 0
+    flops = 0
+    for i, c in enumerate(tl.mids):
+        off, rows, cols = tl.mats[c][:3]
+        tr = rows < cols
+        m, nn = (cols, rows) if tr else (rows, cols)
+        desc[i] = (go, vo, so, m, nn)
+        st = stage[i]
+        st["dst_off"], st["src_off"], st["idx_off"], st["scl_off"] = go, off, -1, -1
+        st["rows"], st["cols"], st["ldd"], st["lds"] = m, nn, m, rows
+        st["op"], st["gather_dim"], st["scale_dim"], st["inv_norm"] = (OP_C if tr else OP_N), 0, -1, 0
+        transposed.append(tr)
+        go += m * nn
+        vo += nn * nn
+        so += nn
+        max_m = max(max_m, m)
+        flops += 4 * (4 * m * nn * nn + 8 * nn ** 3)
+    return SvdPlan(desc[:max(n, 1)], stage[:max(n, 1)], list(tl.mids), transposed, go, vo, so, max_m, flops)
+
+
+def truncate(svals: dict, chi_full=None, cutoff=0.0, weighting="sqrtdim", rel_floor=1e-14):
+    """Global truncation over sectors.  svals: c -> singular values of the
+    tilde-normalised block in DESCENDING order.  Schmidt value = s / sqrt(2S+1), each
+    (2S+1)-fold degenerate.
+      cutoff   -> truncbelow(10^-svalue), src:1007-1010 (keep Schmidt values > cutoff)
+      chi_full -> truncdim(D), src:1363-1365 (largest values while sum (2S+1) kept <= D)
+    Returns (keep: c -> count, discarded weight, norm of the kept part)."""
+    smax = max((float(s[0]) for s in svals.values() if len(s)), default=0.0)
+    items = []
+    for c, s in svals.items():
+        d = c[1] + 1
+        sd = sqrt(d)
+        for i, v in enumerate(s):
+            v = float(v)
+            if v / sd <= cutoff or v <= rel_floor * smax:
+                continue
+            items.append((-(v if weighting == "sqrtdim" else v / sd), c, i, d))
+    items.sort()
+    keep = {c: 0 for c in svals}
+    tot = 0
+    for key, c, i, d in items:
+        if chi_full is not None and tot + d > chi_full:
+            break
+        keep[c] += 1
+        tot += d
+    total = sum(float(np.sum(np.asarray(s, dtype=float) ** 2)) for s in svals.values())
+    kept = sum(float(np.sum(np.asarray(svals[c][:keep[c]], dtype=float) ** 2)) for c in svals)
+    return keep, (total - kept) / total if total > 0 else 0.0, sqrt(kept)
+
+
+def plan_finalize(tl: ThetaLayout, sp: SvdPlan, order: dict, keep: dict, layA: SiteLayout, layB: SiteLayout,
+                  placement: str):
+    """copy items writing the truncated A (left layout, BUF dst A) and B (right layout, dst B).
+    order[c] = permutation sorting the Jacobi column norms descending; keep[c] = kept count.
+    Returns (itemsA_from_G, itemsA_from_V, itemsB_from_G, itemsB_from_V, idx array)."""
+    idx = []
+    A_g, A_v, B_g, B_v = [], [], [], []
+    for i, c in enumerate(sp.mids):
+        k = keep.get(c, 0)
+        if k == 0:
+            continue
+        off, rows, cols = tl.mats[c][:3]
+        g_off, v_off, s_off, m, nn = (int(x) for x in sp.desc[i])
+        ioff = len(idx)
+        idx.extend(int(p) for p in order[c][:k])
+        oA = layA.mats[c][0]
+        oB = layB.mats[c][0]
+        tr = sp.transposed[i]
+        itA = np.zeros((), dtype=COPY_DT)
+        itB = np.zeros((), dtype=COPY_DT)
+        # A (rows x k), ld rows.  U = G'[:,p]/sigma (not transposed) or J[:,p] (transposed)
+        itA["dst_off"], itA["rows"], itA["cols"], itA["ldd"] = oA, rows, k, rows
+        itA["idx_off"], itA["gather_dim"], itA["op"] = ioff, 1, OP_N
+        itA["scl_off"] = s_off
+        if not tr:
+            itA["src_off"], itA["lds"] = g_off, m
+            itA["scale_dim"], itA["inv_norm"] = (1, 1) if placement == "right" else (-1, 0)
+            A_g.append(itA)
+        else:
+            itA["src_off"], itA["lds"] = v_off, nn
+            itA["scale_dim"], itA["inv_norm"] = (-1, 0) if placement == "right" else (1, 0)
+            A_v.append(itA)
+        # B (k x cols), ld k.  V^H = conj(J[:,p])^T (not transposed) or conj(G'[:,p])^T/sigma (transposed)
+        itB["dst_off"], itB["rows"], itB["cols"], itB["ldd"] = oB, k, cols, k
+        itB["idx_off"], itB["gather_dim"], itB["op"] = ioff, 0, OP_C
+        itB["scl_off"] = s_off
+        if not tr:
+            itB["src_off"], itB["lds"] = v_off, nn
+            itB["scale_dim"], itB["inv_norm"] = (0, 0) if placement == "right" else (-1, 0)
+            B_v.append(itB)
+        else:
+            itB["src_off"], itB["lds"] = g_off, m
+            itB["scale_dim"], itB["inv_norm"] = (-1, 0) if placement == "right" else (0, 1)
+            B_g.append(itB)
+
+    def arr(lst):
+        return np.array(lst, dtype=COPY_DT) if lst else np.zeros(0, dtype=COPY_DT)
+    return arr(A_g), arr(A_v), arr(B_g), arr(B_v), np.array(idx if idx else [0], dtype=np.int32)

@@ -1,0 +1,133 @@
+/* hubbardtn_hip.h -- C ABI of libhubbardtn_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the two-site DMRG hot path that HubbardTN reaches through
+ *     find_groundstate(psi0, H, IDMRG2(...))            src/HubbardFunctions.jl:1010
+ * i.e. the work MPSKit 0.13.1 / TensorKit 0.14.6 / KrylovKit 0.9.5 do per bond update
+ * (SURVEY.md section 8a rows a7-a10).  Those packages are not vendored under /root/reference;
+ * each entry point below names the dependency routine it stands in for and the reference call
+ * site that reaches it.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; sizes are element counts
+ *   - complex128 = interleaved (re, im) doubles, exactly Julia's Vector{ComplexF64}
+ *     (src/HubbardFunctions.jl:264 ff. build every TensorMap as ComplexF64)
+ *   - matrices are column-major with an explicit leading dimension (TensorKit block layout)
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued, nothing synchronises
+ *     unless stated
+ *   - return value 0 = ok, otherwise htn_last_error() (thread-local) describes the failure
+ *   - no exceptions cross the boundary; no global mutable state except the error string
+ */
+#ifndef HUBBARDTN_HIP_H
+#define HUBBARDTN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HTN_ABI_VERSION 1
+#define HTN_MAX_BUFS 8
+#define HTN_TILE 32              /* output tile edge of the grouped GEMM */
+
+/* operand ops */
+#define HTN_OP_N 0               /* as stored                        */
+#define HTN_OP_T 1               /* transposed                       */
+#define HTN_OP_C 2               /* conjugate transposed             */
+/* segment types */
+#define HTN_SEG_GEMM 0           /* C += alpha * op(A) * op(B)       */
+#define HTN_SEG_COPY 1           /* C += alpha * B  (B is m x n)     */
+
+/* One output tile (<= 32 x 32) of an output block.  The tile owns segs[seg_begin .. +seg_count)
+ * and is WRITTEN (not accumulated): a tile with no segments stores zeros. */
+typedef struct {
+    int64_t c_off;      /* element offset of the BLOCK origin inside bufs[buf_c]   */
+    int32_t buf_c;      /* index into the buffer table                              */
+    int32_t ldc;
+    int32_t m, n;       /* extent of this tile (1..32)                              */
+    int32_t row0, col0; /* tile origin inside the block                             */
+    int32_t seg_begin, seg_count;
+    int32_t pad[2];
+} htn_tile;             /* 48 bytes */
+
+/* One contribution  alpha * op(A)[block rows, 0:k] * op(B)[0:k, block cols]  to an output block.
+ * op(A) is (block rows x k), op(B) is (k x block cols); offsets address element (0,0) of op(.). */
+typedef struct {
+    int64_t a_off, b_off;
+    int32_t buf_a, buf_b;
+    int32_t lda, ldb;
+    int32_t k;
+    int32_t op_a, op_b;
+    int32_t type;
+    double alpha_re, alpha_im;
+} htn_seg;              /* 64 bytes */
+
+const char* htn_last_error(void);
+int htn_abi_version(void);
+
+/* Binds the calling thread to a device and returns its properties (name buffer >= 256 bytes). */
+int htn_device_init(int device, char* name_host, int* cu_count_host);
+
+/* Grouped, segmented complex128 GEMM on v_mfma_f64_16x16x4_f64.
+ * Stands in for: TensorKit block mul! (BLAS zgemm per coupled sector) + the TensorOperations /
+ * Strided permutes around it, as executed inside MPSKit's AC2 effective-Hamiltonian apply and
+ * environment transfers (reached from src/HubbardFunctions.jl:1010).
+ * bufs_host: HTN_MAX_BUFS device base pointers (unused entries may be NULL).
+ * If tile_ms_dev != NULL it must hold n_tiles floats and is left untouched (reserved). */
+int htn_grouped_gemm_z(const void* const* bufs_host, const htn_tile* tiles, int32_t n_tiles,
+                       const htn_seg* segs, void* stream);
+
+/* Krylov vector algebra (stands in for VectorInterface inner/add!!/scale!! on TensorMaps as used
+ * by KrylovKit.eigsolve(..., Lanczos)).  The reduced data are stored in the
+ * Euclidean ("tilde") normalisation, so TensorKit's dim-weighted inner product is the plain dot.
+ *   out[i]  = sum_j conj(V[i*ldv + j]) * w[j]        i < nvec      (deterministic 2-stage reduce)
+ *   w[j]   += sign * sum_i coef[i] * V[i*ldv + j]
+ * scratch must hold htn_dots_scratch_elems(nvec) complex128. */
+int64_t htn_dots_scratch_elems(int32_t nvec);
+int htn_dots_z(const void* V, int64_t ldv, int32_t nvec, const void* w, int64_t n,
+               void* out, void* scratch, void* stream);
+int htn_axpys_z(void* w, const void* V, int64_t ldv, int32_t nvec, const void* coef,
+                double sign, int64_t n, void* stream);
+/* dst[j] = src[j] / sqrt(Re(nrm2[0]))  (nrm2 on device; dst may alias src) */
+int htn_scale_inv_sqrt_z(void* dst, const void* src, const void* nrm2, int64_t n, void* stream);
+
+/* Batched one-sided Jacobi SVD of the coupled-sector blocks of a two-site tensor.
+ * Stands in for: TensorKit tsvd!(t; alg=SVD()) -> LAPACK zgesvd per block (SURVEY.md 8a a9,
+ * scheme chosen at src/HubbardFunctions.jl:1010 and :1363-1365).
+ * For block i the m_i x n_i (m_i >= n_i, column-major, ld = m_i) matrix at G + g_off[i] is
+ * overwritten by G*J (mutually orthogonal columns), the n_i x n_i rotation J is written at
+ * Vj + v_off[i] (ld = n_i), and the UNSORTED column norms at S + s_off[i].
+ * The caller transposes blocks with rows < cols beforehand (htn_svd_finalize undoes it).
+ * desc: device array of htn_svd_block; max_m_host = max_i m_i (<= 512 in this version).
+ * info_dev[i] receives the sweep count (<0: not converged). */
+typedef struct {
+    int64_t g_off, v_off, s_off;
+    int32_t m, n;
+} htn_svd_block;        /* 32 bytes */
+int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc, int32_t n_blocks,
+                     int32_t max_m_host, int32_t max_sweeps, double tol, int32_t* info_dev, void* stream);
+
+/* dst(r x c, ldd) = op(src)(.., lds) with optional per-row / per-column real scaling:
+ * generic batched strided copy used to (a) stage M or M^H into the Jacobi workspace and
+ * (b) write the truncated isometries U[:, keep] / V^H[keep, :] and the centre S*V^H / U*S.
+ * For each item: dst[i + j*ldd] = scale * f(src element), where
+ *   op N: src[(i) + perm(j)*lds]      op C: conj(src[perm(j)... see htn_copy_item]). */
+typedef struct {
+    int64_t dst_off, src_off, idx_off, scl_off; /* idx/scl offsets into int32 / double side arrays; -1 = none */
+    int32_t rows, cols;          /* extent of dst                                   */
+    int32_t ldd, lds;
+    int32_t op;                  /* HTN_OP_N: dst(i,j) = src(i, J) ; HTN_OP_C: dst(i,j) = conj(src(J', i))
+                                    where the gathered index (idx side array) applies to dst's
+                                    `gather_dim` (0 = rows, 1 = cols)                 */
+    int32_t gather_dim;
+    int32_t scale_dim;           /* 0: scale by scl[i], 1: scale by scl[j], -1: none  */
+    int32_t inv_norm;            /* 1: divide by the gathered scale value instead     */
+} htn_copy_item;        /* 64 bytes */
+int htn_batched_copy_z(void* dst, const void* src, const int32_t* idx, const double* scl,
+                       const htn_copy_item* items, int32_t n_items, double global_scale,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,160 @@
+"""GPU parity of every C-ABI primitive against its numpy statement (tests/emul.py)."""
+import numpy as np
+import pytest
+
+from emul import NumpyOps
+from hubbardtn_amd import abi
+from hubbardtn_amd.planner import TaskList
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_z(rng, n):
+    return rng.standard_normal(n) + 1j * rng.standard_normal(n)
+
+
+def _random_tasks(rng, nblocks, maxdim, maxk, nbuf_elems):
+    """random grouped-GEMM problem exercising all ops, ragged sizes, COPY segments, empty blocks"""
+    tl = TaskList()
+    out_off = 0
+    for b in range(nblocks):
+        m, n = int(rng.integers(1, maxdim)), int(rng.integers(1, maxdim))
+        ld = m + int(rng.integers(0, 3))
+        tl.block(b, 1, out_off, m, n, ld)
+        out_off += ld * n
+        for s in range(int(rng.integers(0, 5))):
+            alpha = complex(rng.standard_normal(), rng.standard_normal())
+            if rng.random() < 0.2:
+                ldb = m + int(rng.integers(0, 4))
+                off = int(rng.integers(0, nbuf_elems - ldb * n - 1))
+                tl.copy(b, 0, off, ldb, alpha)
+                continue
+            k = int(rng.integers(1, maxk))
+            op_a, op_b = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+            lda = (m if op_a == abi.OP_N else k) + int(rng.integers(0, 3))
+            ldb = (k if op_b == abi.OP_N else n) + int(rng.integers(0, 3))
+            sa = lda * (k if op_a == abi.OP_N else m)
+            sb = ldb * (n if op_b == abi.OP_N else k)
+            a_off = int(rng.integers(0, nbuf_elems - sa - 1))
+            b_off = int(rng.integers(0, nbuf_elems - sb - 1))
+            tl.gemm(b, 0, a_off, lda, op_a, 2, b_off, ldb, op_b, k, alpha)
+    return tl.finalize(), out_off
+
+
+@pytest.mark.parametrize("seed,nblocks,maxdim,maxk", [(0, 40, 20, 30), (1, 25, 75, 90), (2, 6, 140, 300)])
+def test_grouped_gemm_matches_numpy(hip_ops, seed, nblocks, maxdim, maxk):
+    rng = np.random.default_rng(seed)
+    nel = 200_000
+    tasks, out_size = _random_tasks(rng, nblocks, maxdim, maxk, nel)
+    src0, src2 = _rand_z(rng, nel), _rand_z(rng, nel)
+    ref = np.zeros(out_size, dtype=np.complex128)
+    emu = NumpyOps()
+    emu.grouped_gemm([src0, ref, src2] + [None] * 5, emu.upload_tasks(tasks))
+    d0, d2 = hip_ops.to_device(src0), hip_ops.to_device(src2)
+    out = hip_ops.zeros_z(out_size)
+    hip_ops.grouped_gemm([d0, out, d2] + [None] * 5, hip_ops.upload_tasks(tasks))
+    got = hip_ops.to_host(out)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-12 * scale      # f64 MFMA, tolerance = accumulation order only
+
+
+def test_mfma_layout_identity_asymmetric(hip_ops):
+    """A = I with an asymmetric B catches a transposed C/D lane map (cdna guide section 3)"""
+    n = 32
+    tl = TaskList()
+    tl.block(0, 1, 0, n, n, n)
+    tl.gemm(0, 0, 0, n, abi.OP_N, 2, 0, n, abi.OP_N, n, 1.0)
+    tasks = tl.finalize()
+    I = np.eye(n, dtype=np.complex128).T.reshape(-1)
+    B = (np.arange(n)[:, None] * 100 + np.arange(n)[None, :]) * (1 + 0.5j)
+    out = hip_ops.zeros_z(n * n)
+    hip_ops.grouped_gemm([hip_ops.to_device(I), out, hip_ops.to_device(B.T.reshape(-1).copy())] + [None] * 5,
+                         hip_ops.upload_tasks(tasks))
+    got = hip_ops.to_host(out).reshape(n, n).T
+    assert np.array_equal(got, B)
+
+
+def test_krylov_vector_algebra(hip_ops):
+    rng = np.random.default_rng(3)
+    n, nv = 54_321, 17
+    V = _rand_z(rng, nv * n)
+    w = _rand_z(rng, n)
+    dV, dw = hip_ops.to_device(V), hip_ops.to_device(w)
+    out = hip_ops.zeros_z(nv)
+    hip_ops.dots(dV, n, nv, dw, n, out)
+    ref = np.array([np.vdot(V[i * n:(i + 1) * n], w) for i in range(nv)])
+    got = hip_ops.to_host(out)
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    out2 = hip_ops.zeros_z(nv)
+    hip_ops.dots(dV, n, nv, dw, n, out2)
+    assert np.array_equal(hip_ops.to_host(out2), got)          # deterministic reduction order
+    coef = _rand_z(rng, nv)
+    hip_ops.axpys(dw, dV, n, nv, hip_ops.to_device(coef), -1.0, n)
+    wref = w - (coef[:, None] * V.reshape(nv, n)).sum(0)
+    assert np.abs(hip_ops.to_host(dw) - wref).max() <= 1e-12 * np.abs(wref).max()
+    nr = hip_ops.zeros_z(1)
+    hip_ops.dots(dw, n, 1, dw, n, nr)
+    hip_ops.scale_inv_sqrt(dw, dw, nr, n)
+    assert abs(np.linalg.norm(hip_ops.to_host(dw)) - 1.0) < 1e-13
+
+
+@pytest.mark.parametrize("shapes", [[(1, 1), (2, 1), (5, 5), (17, 9), (64, 64), (70, 33)], [(130, 130), (200, 90), (3, 2)]])
+def test_jacobi_svd_matches_lapack(hip_ops, shapes):
+    rng = np.random.default_rng(4)
+    desc = np.zeros(len(shapes), dtype=abi.SVD_DT)
+    go = vo = so = 0
+    mats = []
+    for i, (m, n) in enumerate(shapes):
+        desc[i] = (go, vo, so, m, n)
+        # graded spectrum like a Schmidt spectrum: singular values over 12 decades
+        U, _ = np.linalg.qr(_rand_z(rng, m * n).reshape(m, n))
+        W, _ = np.linalg.qr(_rand_z(rng, n * n).reshape(n, n))
+        s = 10.0 ** (-12 * np.arange(n) / max(n - 1, 1))
+        mats.append((U * s) @ W.conj().T)
+        go, vo, so = go + m * n, vo + n * n, so + n
+    G = np.concatenate([M.T.reshape(-1) for M in mats])
+    dG = hip_ops.to_device(G)
+    dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
+    hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), max(m for m, _ in shapes), 40, 1e-14, info)
+    Gp, J, S, inf = hip_ops.to_host(dG), hip_ops.to_host(dV), hip_ops.to_host(dS), hip_ops.to_host(info)
+    assert inf.min() > 0, inf
+    for i, (m, n) in enumerate(shapes):
+        d = desc[i]
+        gp = Gp[d["g_off"]:d["g_off"] + m * n].reshape(n, m).T
+        j = J[d["v_off"]:d["v_off"] + n * n].reshape(n, n).T
+        s = S[d["s_off"]:d["s_off"] + n]
+        ref = np.linalg.svd(mats[i], compute_uv=False)
+        got = np.sort(s)[::-1]
+        # high RELATIVE accuracy of one-sided Jacobi, also for the tiny values
+        assert np.abs(got - ref).max() <= 1e-13 * ref[0]
+        big = ref > 1e-9
+        assert np.abs(got[big] / ref[big] - 1).max() < 1e-8
+        assert np.abs(j.conj().T @ j - np.eye(n)).max() < 1e-13          # J unitary
+        assert np.abs(mats[i] @ j - gp).max() < 1e-13                     # G' = M J
+        gram = gp.conj().T @ gp
+        off = gram - np.diag(np.diag(gram))
+        assert np.abs(off).max() <= 1e-13 * ref[0] ** 2 + 1e-13 * np.sqrt(np.outer(np.diag(gram).real, np.diag(gram).real)).max()
+
+
+def test_batched_copy_matches_numpy(hip_ops):
+    rng = np.random.default_rng(5)
+    src = _rand_z(rng, 5000)
+    scl = rng.random(200) + 0.5
+    idx = rng.integers(0, 9, size=64).astype(np.int32)
+    items = np.zeros(6, dtype=abi.COPY_DT)
+    cfg = [(abi.OP_N, 1, 1, 1), (abi.OP_N, 1, -1, 0), (abi.OP_C, 0, 0, 0), (abi.OP_C, 0, 0, 1), (abi.OP_N, 0, -1, 0),
+           (abi.OP_C, 1, -1, 0)]
+    off = 0
+    for k, (op, gd, sd, inv) in enumerate(cfg):
+        rows, cols = 7 + k, 5 + 2 * k
+        it = items[k]
+        it["dst_off"], it["src_off"], it["idx_off"], it["scl_off"] = off, 100 * k, (3 * k if k != 4 else -1), 10 * k
+        it["rows"], it["cols"], it["ldd"], it["lds"] = rows, cols, rows + 1, 23
+        it["op"], it["gather_dim"], it["scale_dim"], it["inv_norm"] = op, gd, sd, inv
+        off += (rows + 1) * cols
+    ref = np.zeros(off, dtype=np.complex128)
+    NumpyOps().batched_copy(ref, src, idx, scl, items, len(items), 0.7)
+    dst = hip_ops.zeros_z(off)
+    hip_ops.batched_copy(dst, hip_ops.to_device(src), hip_ops.to_device(idx), hip_ops.to_device(scl),
+                         hip_ops.to_device(items), len(items), 0.7)
+    assert np.abs(hip_ops.to_host(dst) - ref).max() < 1e-14
