@@ -49,6 +49,9 @@ def load_library(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # torch ships its own libamdhip64; it must be in the process BEFORE our library is dlopen'ed so
+    # that both bind to ONE HIP runtime (two runtimes in one process cannot both see the device)
+    import torch  # noqa: F401
     if not os.path.exists(p):
         raise HtnError(f"{p} not found: build it with `python -m hubbardtn_amd.build` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")

@@ -32,6 +32,7 @@ class HipOps:
         self.arch = name.value.decode()
         self.cu_count = cus.value
         self._dots_scratch = None
+        self.event_log = None        # bench.py: list of (start_event, end_event, tag, flops)
 
     # ---- memory -----------------------------------------------------------------------------
     def empty_z(self, n):
@@ -76,13 +77,21 @@ class HipOps:
         """tasks: planner.Tasks -> (tiles_dev, ntiles, segs_dev)"""
         return (self.to_device(tasks.tiles), tasks.ntiles, self.to_device(tasks.segs))
 
-    def grouped_gemm(self, bufs, dev_tasks):
+    def grouped_gemm(self, bufs, dev_tasks, tag=None, flops=0):
         tiles, ntiles, segs = dev_tasks
         if ntiles == 0:
             return
         table = (C.c_void_p * abi.HTN_MAX_BUFS)(*[0 if b is None else b.data_ptr() for b in bufs])
+        log = self.event_log is not None and tag is not None
+        if log:      # HIP events on the launch stream (torch's current stream IS the launch stream)
+            e0 = self.torch.cuda.Event(enable_timing=True)
+            e1 = self.torch.cuda.Event(enable_timing=True)
+            e0.record()
         abi.check(self.lib, self.lib.htn_grouped_gemm_z(table, self._p(tiles), ntiles, self._p(segs),
                                                         self._stream()), "htn_grouped_gemm_z")
+        if log:
+            e1.record()
+            self.event_log.append((e0, e1, tag, flops))
 
     def dots(self, V, ldv, nvec, w, n, out):
         need = self.lib.htn_dots_scratch_elems(64)

@@ -172,8 +172,8 @@ class DMRG2:
             if self.shard is not None:
                 ops.zero(y)
             if dz is not None:
-                ops.grouped_gemm(self._bufs(x=x, l=Lb, z=z), dz)
-            ops.grouped_gemm(self._bufs(x=x, y=y, l=Lb, r=Rb, z=z), dy)
+                ops.grouped_gemm(self._bufs(x=x, l=Lb, z=z), dz, tag="apply_z", flops=tz.flops)
+            ops.grouped_gemm(self._bufs(x=x, y=y, l=Lb, r=Rb, z=z), dy, tag="apply", flops=ty.flops)
             if self.shard is not None:
                 self.shard[2](y)
         flops = ty.flops + (tz.flops if tz is not None else 0)

@@ -422,11 +422,12 @@ def truncate_spectrum(svals, chi_full=None, cutoff=0.0, weighting="sqrtdim"):
     Returns c -> number kept, and the discarded weight sum s^2 (state normalised to 1).
     """
     items = []
+    smax = max((float(s[0]) for s in svals.values() if len(s)), default=0.0)
     for c, s in svals.items():
         d = c[1] + 1
         for i, v in enumerate(s):
             schmidt = v / np.sqrt(d)
-            if schmidt <= cutoff:
+            if schmidt <= cutoff or v <= 1e-14 * smax:     # numerically zero directions are never kept
                 continue
             key = v if weighting == "sqrtdim" else schmidt
             items.append((key, c, i, d))
@@ -515,7 +516,10 @@ class DMRG2:
                 theta[beta] = np.zeros((bl[a], br[b]), dtype=CDT)
         return theta
 
-    def update_bond(self, i, direction):
+    def update_bond(self, i, direction, placement=None):
+        """placement 'right': A_i = U, centre S V^H on site i+1; 'left': centre U S on i, B_{i+1} = V^H"""
+        if placement is None:
+            placement = "right" if direction > 0 else "left"
         psi = self.psi
         bl, br = psi.bonds[i], psi.bonds[i + 2]
         theta = self._theta(i, direction)
@@ -533,7 +537,7 @@ class DMRG2:
         theta = _unflat(x, blocks, shapes)
         A, S, B, mid, tw, svals = svd_truncate(theta, bl, br, self.chi_full, self.cutoff, self.weighting)
         psi.bonds[i + 1] = mid
-        if direction > 0:
+        if placement == "right":
             psi.tensors[i] = A
             psi.kinds[i] = "L"
             psi.tensors[i + 1] = {k: S[k[0]][:, None] * v for k, v in B.items()}   # centre on site i+1
@@ -551,12 +555,14 @@ class DMRG2:
         return E, {c: S[c] / np.sqrt(c[1] + 1) for c in S}
 
     def sweep(self):
-        """one full sweep L->R then R->L: 2(L-1) bond updates (SURVEY 8(d) metric)"""
+        """one sweep in MPSKit's DMRG2 order (App. A.4): bonds 1..L-1 rightwards, then L-2..1
+        leftwards = 2L-3 bond updates; the last rightward update leaves the centre on the left."""
         spectra = {}
-        for i in range(self.L - 1):
-            E, sp = self.update_bond(i, +1)
+        L = self.L
+        for i in range(L - 1):
+            E, sp = self.update_bond(i, +1, "right" if i < L - 2 else "left")
             spectra[i + 1] = sp
-        for i in range(self.L - 2, -1, -1):
-            E, sp = self.update_bond(i, -1)
+        for i in range(L - 3, -1, -1):
+            E, sp = self.update_bond(i, -1, "left")
             spectra[i + 1] = sp
         return self.energy, spectra

@@ -53,7 +53,7 @@ class NumpyOps:
         v = buf[off + j + i * ld]
         return v.conj() if op == abi.OP_C else v
 
-    def grouped_gemm(self, bufs, dev_tasks):
+    def grouped_gemm(self, bufs, dev_tasks, tag=None, flops=0):
         tiles, ntiles, segs = dev_tasks
         self.launches += 1
         outs = []

@@ -117,7 +117,7 @@ def test_jacobi_svd_matches_lapack(hip_ops, shapes):
     dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
     hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), max(m for m, _ in shapes), 40, 1e-14, info)
     Gp, J, S, inf = hip_ops.to_host(dG), hip_ops.to_host(dV), hip_ops.to_host(dS), hip_ops.to_host(info)
-    assert inf.min() > 0, inf
+    assert inf.min() >= 0, inf          # negative = not converged; 0 = nothing to do (n < 2)
     for i, (m, n) in enumerate(shapes):
         d = desc[i]
         gp = Gp[d["g_off"]:d["g_off"] + m * n].reshape(n, m).T
@@ -125,9 +125,10 @@ def test_jacobi_svd_matches_lapack(hip_ops, shapes):
         s = S[d["s_off"]:d["s_off"] + n]
         ref = np.linalg.svd(mats[i], compute_uv=False)
         got = np.sort(s)[::-1]
-        # high RELATIVE accuracy of one-sided Jacobi, also for the tiny values
+        # LAPACK (the reference's zgesvd) is accurate to eps * sigma_max ABSOLUTE only, so the relative
+        # 1e-8 bar of north_star is checkable against it down to sigma ~ 1e-6 sigma_max
         assert np.abs(got - ref).max() <= 1e-13 * ref[0]
-        big = ref > 1e-9
+        big = ref > 1e-6 * ref[0]
         assert np.abs(got[big] / ref[big] - 1).max() < 1e-8
         assert np.abs(j.conj().T @ j - np.eye(n)).max() < 1e-13          # J unitary
         assert np.abs(mats[i] @ j - gp).max() < 1e-13                     # G' = M J
