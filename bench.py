@@ -35,8 +35,10 @@ def parse():
     ap.add_argument("--L", type=int, default=64)
     ap.add_argument("--U", type=float, default=4.0)
     ap.add_argument("--chi", type=int, default=512)
-    ap.add_argument("--grow", type=str, default="64,128,256")
-    ap.add_argument("--grow-sweeps", type=int, default=2)
+    ap.add_argument("--grow", type=str, default="16x8,32x4,64x4,128x2,256x2",
+                    help="untimed growth schedule chi x sweeps (state preparation, loose Lanczos)")
+    ap.add_argument("--grow-tol", type=float, default=1e-6)
+    ap.add_argument("--profile", action="store_true", help="sync-bracketed per-stage host timers (perturbs timing)")
     ap.add_argument("--lanczos-tol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bonds", type=int, default=1)
@@ -108,13 +110,20 @@ def main():
     bonds, tens = mps.random_mps(L, (L, 0), 4, seed=1234)
     eng = engine.DMRG2(ops, mpo, bonds, tens, chi_full=16, lanczos_tol=args.lanczos_tol, shard=shard)
     t_start = time.perf_counter()
-    for chi in [int(x) for x in args.grow.split(",") if x] + [args.chi]:
-        eng.chi_full = min(chi, args.chi)
-        nsw = args.grow_sweeps if chi != args.chi else 0
+    eng.lanczos_tol = args.grow_tol
+    for item in [x for x in args.grow.split(",") if x]:
+        chi, nsw = (int(v) for v in item.split("x"))
+        if chi >= args.chi:
+            continue
+        eng.chi_full = chi
         for _ in range(nsw):
             t0 = time.perf_counter()
             E = eng.sweep()
-            log(f"grow chi={eng.chi_full} E/L={E / L:.10f} {time.perf_counter() - t0:.2f}s")
+            log(f"grow chi={eng.chi_full} E/L={E / L:.10f} {time.perf_counter() - t0:.2f}s "
+                f"mv={sum(s.n_matvec for s in eng.stats[-(2 * L - 3):])}")
+    eng.chi_full = args.chi
+    eng.lanczos_tol = args.lanczos_tol
+    eng.profile = args.profile
     for _ in range(args.warmup):
         t0 = time.perf_counter()
         E = eng.sweep()
@@ -163,6 +172,10 @@ def main():
         "matvecs_per_sweep": tot_mv / args.steps,
         "max_trunc_weight": max(s.trunc_weight for s in stats),
         "host_plan_s_per_sweep": sum(s.t_plan for s in stats) / args.steps,
+        "stage_s_per_sweep": {"plan+theta": sum(s.t_plan for s in stats) / args.steps,
+                              "lanczos": sum(s.t_lanczos for s in stats) / args.steps,
+                              "svd+truncate": sum(s.t_svd for s in stats) / args.steps,
+                              "env": sum(s.t_env for s in stats) / args.steps} if args.profile else None,
         "roofline": {"bound": "mfma", "kernel": "k_grouped_gemm_z (H_eff apply)", "achieved": achieved,
                      "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F64_MFMA_TFLOPS,
                      "traffic": None, "launches": k_n, "avg_launch_us": (k_ms * 1e3 / k_n) if k_n else None,

@@ -40,6 +40,9 @@ class BondStats:
     n_segs: int
     t_plan: float = 0.0
     t_total: float = 0.0
+    t_lanczos: float = 0.0
+    t_svd: float = 0.0
+    t_env: float = 0.0
 
 
 def _tridiag_lowest(alphas, betas):
@@ -71,6 +74,7 @@ class DMRG2:
         self.krylovdim, self.lanczos_tol, self.maxrestart = krylovdim, lanczos_tol, maxrestart
         self.jacobi_tol, self.jacobi_max_sweeps = jacobi_tol, jacobi_max_sweeps
         self.shard = shard
+        self.profile = False
         self.bonds = [Bond(b) for b in bonds]
         self.site_lay = [None] * self.L
         self.site_buf = [None] * self.L
@@ -248,8 +252,13 @@ class DMRG2:
         ops.dots(V[0:n], n, 1, V[0:n], n, nr)
         ops.scale_inv_sqrt(V[0:n], V[0:n], nr, n)
         apply, aflops, abytes, ntiles, nsegs = self._make_apply(i, tl)
+        if self.profile:
+            ops.sync()
         t_plan = time.perf_counter() - t0
         E, nmv, res = self._lanczos(apply, V, n, scal)
+        if self.profile:
+            ops.sync()
+        t_lan = time.perf_counter() - t0 - t_plan
         x = V[0:n]
         # ---- SVD + truncation ----
         sp = pl.plan_svd(tl)
@@ -292,17 +301,24 @@ class DMRG2:
         self.bonds[i + 1] = mid
         self.site_lay[i], self.site_buf[i] = layA, bufA
         self.site_lay[i + 1], self.site_buf[i + 1] = layB, bufB
+        if self.profile:
+            ops.sync()
+        t_svd = time.perf_counter() - t0 - t_plan - t_lan
         if placement == "right":
             self._left_env(i)
         else:
             self._right_env(i + 1)
+        if self.profile:
+            ops.sync()
+        t_env = time.perf_counter() - t0 - t_plan - t_lan - t_svd
         self.energy = E
         self.spectra[i + 1] = {c: svals[c][:keep[c]] / nrm / np.sqrt(c[1] + 1) for c in svals if keep[c] > 0}
         st = BondStats(bond=i + 1, direction=direction, energy=E, n_matvec=nmv, residual=res, trunc_weight=tw,
                        chi_full=mid.dim_full, multiplets=mid.multiplets, theta_size=n, apply_flops=aflops,
                        apply_bytes=abytes, svd_flops=sp.flops,
                        jacobi_sweeps=int(info_h[:nb].max()) if nb else 0, n_tiles=ntiles, n_segs=nsegs,
-                       t_plan=t_plan, t_total=time.perf_counter() - t0)
+                       t_plan=t_plan, t_total=time.perf_counter() - t0, t_lanczos=t_lan, t_svd=t_svd,
+                       t_env=t_env)
         self.stats.append(st)
         return E
 

@@ -12,10 +12,12 @@ import numpy as np
 from .planner import full_bonds, fuse
 
 
-def random_mps(nsites, target, max_dimension, seed=1234):
-    """returns (bonds: list[dict], tensors: list[dict (l,s,r) -> ndarray])"""
+def random_mps(nsites, target, max_dimension, seed=1234, max_twoS=6):
+    """returns (bonds: list[dict], tensors: list[dict (l,s,r) -> ndarray]).
+    max_twoS = 6 is the reference's S <= 3 cap on the initial virtual spaces (src:933)."""
     rng = np.random.default_rng(seed)
-    bonds = [{sec: min(n, max_dimension) for sec, n in b.dims.items()} for b in full_bonds(nsites, target)]
+    bonds = [{sec: min(n, max_dimension) for sec, n in b.dims.items() if sec[1] <= max_twoS}
+             for b in full_bonds(nsites, target)]
     tensors = [None] * nsites
     for i in range(nsites - 1, -1, -1):
         bl, br = bonds[i], bonds[i + 1]

@@ -595,8 +595,8 @@ def truncate(svals: dict, chi_full=None, cutoff=0.0, weighting="sqrtdim", rel_fl
     keep = {c: 0 for c in svals}
     tot = 0
     for key, c, i, d in items:
-        if chi_full is not None and tot + d > chi_full:
-            break
+        if chi_full is not None and tot + d > chi_full and tot > 0:
+            break               # (the largest multiplet is always kept, even if wider than chi_full)
         keep[c] += 1
         tot += d
     total = sum(float(np.sum(np.asarray(s, dtype=float) ** 2)) for s in svals.values())

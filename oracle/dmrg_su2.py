@@ -436,7 +436,7 @@ def truncate_spectrum(svals, chi_full=None, cutoff=0.0, weighting="sqrtdim"):
     keep = {c: 0 for c in svals}
     tot = 0
     for key, c, i, d in items:
-        if chi_full is not None and tot + d > chi_full:
+        if chi_full is not None and tot + d > chi_full and tot > 0:
             break           # stop at the first multiplet that does not fit (contiguous prefix)
         # values within a sector arrive in descending order, so kept sets are prefixes
         keep[c] += 1
