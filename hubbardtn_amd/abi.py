@@ -34,7 +34,16 @@ assert TILE_DT.itemsize == 48 and SEG_DT.itemsize == 64 and SVD_DT.itemsize == 3
 
 EXPORTS = ["htn_last_error", "htn_abi_version", "htn_device_init", "htn_grouped_gemm_z",
            "htn_dots_scratch_elems", "htn_dots_z", "htn_axpys_z", "htn_scale_inv_sqrt_z",
-           "htn_jacobi_svd_z", "htn_batched_copy_z"]
+           "htn_jacobi_svd_z", "htn_batched_copy_z", "htn_lanczos_scratch_elems", "htn_lanczos_z"]
+
+
+class GemmLaunch(C.Structure):
+    """htn_gemm_launch"""
+    _fields_ = [("bufs", C.c_void_p * HTN_MAX_BUFS), ("tiles", C.c_void_p), ("segs", C.c_void_p),
+                ("n_tiles", C.c_int32), ("pad", C.c_int32)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_void_p)
 
 _lib = None
 
@@ -68,6 +77,10 @@ def load_library(path: str | None = None):
     lib.htn_scale_inv_sqrt_z.argtypes = [vp, vp, vp, i64, vp]
     lib.htn_jacobi_svd_z.argtypes = [vp, vp, vp, vp, i32, i32, i32, f64, vp, vp]
     lib.htn_batched_copy_z.argtypes = [vp, vp, vp, vp, vp, i32, f64, vp]
+    lib.htn_lanczos_scratch_elems.argtypes = [i32]
+    lib.htn_lanczos_scratch_elems.restype = i64
+    lib.htn_lanczos_z.argtypes = [C.POINTER(GemmLaunch), i32, i32, i32, vp, i64, i32, f64, i32, vp, i32,
+                                  EXCHANGE_FN, vp, C.POINTER(f64), C.POINTER(i32), C.POINTER(f64), C.POINTER(f64), vp]
     for name in EXPORTS:
         getattr(lib, name)          # raises AttributeError if a declared symbol is missing
     if lib.htn_abi_version() != 1:

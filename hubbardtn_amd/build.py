@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = os.path.join(HERE, "csrc", "htn_kernels.hip")
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("htn_abi.hip", "htn_gemm.hip", "htn_krylov.hip", "htn_svd.hip")]
 LIB = os.path.join(HERE, "csrc", "libhubbardtn_hip.so")
 INC = os.path.join(ROOT, "include")
 
@@ -16,7 +16,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [SRC, os.path.join(INC, "hubbardtn_hip.h")]
+    deps = SRCS + [os.path.join(HERE, "csrc", "htn_common.h"), os.path.join(INC, "hubbardtn_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -24,7 +24,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INC, SRC, "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INC, *SRCS, "-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -1,0 +1,251 @@
+// grouped, segmented complex128 GEMM on v_mfma_f64_16x16x4_f64 (libhubbardtn_hip.so)
+//
+// Regime: one H_eff apply at chi = 512..2048 is 10^7..10^9 flops spread over a few
+// hundred ragged output tiles -- far too little to fill 256 CUs by output tiles alone, and the f64
+// MFMA is slow (64 clk per 16x16x4), so the critical path is ONE tile's K loop.  The kernel therefore
+// spends a whole 16-wave workgroup on each <=32x32 tile: 4 wave-quads take the tile's K slabs
+// round-robin (intra-workgroup split-K), each quad owns private LDS slab buffers, the next slab's
+// global loads are issued before the current slab's MFMAs (register prefetch), and the 4 partial
+// accumulators are summed through LDS in a fixed order (deterministic).
+//
+// Each segment contributes alpha * op(A) * op(B); alpha is folded into A while staging, so every
+// segment accumulates into the same MFMA accumulators.  K slabs are 16 deep, staged as separate
+// re / im planes.  Each wave owns a 16x16 quadrant and computes it TRANSPOSED (operand roles swapped)
+// so that consecutive lanes hold consecutive rows of the column-major output (256-byte store runs).
+//
+// f64 MFMA lane maps (cdna_hip_programming.md section 3):
+//   A operand: lane l holds Aop[i = l & 15][k = l >> 4]     B operand: Bop[k = l >> 4][j = l & 15]
+//   D: lane l, reg r holds D[row = (l >> 4) + 4 r][col = l & 15]
+// With Aop[i][k] = B[k][c0 + i] and Bop[k][j] = A[r0 + j][k]:  D[i][j] = C[r0 + j][c0 + i].
+#include "htn_common.h"
+
+struct BufTable {
+    double2* p[HTN_MAX_BUFS];
+};
+
+#define KB 16         // K slab depth
+#define NQ 4          // wave-quads per workgroup (split-K ways)
+#define LDS_LD 48     // padded leading dimension (doubles) of a 32-wide slab row: 48 = 16 mod 32 keeps
+                      // the two k-rows read by one 32-lane group on disjoint banks (ds_read_b64)
+// Row kk is additionally rotated by kk inside its 32 doubles: a k-contiguous staging pass (16 lanes
+// writing 16 different kk at one idx) then hits 16 different banks instead of one.
+#define LDS_AT(kk, idx) ((kk) * LDS_LD + (((idx) + (kk)) & 31))
+#define SLAB (KB * LDS_LD)
+
+struct Slab {             // what one thread stages for one K slab: 2 elements of A, 2 of B
+    double2 a[2], b[2];
+};
+
+// cursor of one quad over the tile's GEMM segments: (segment index, k offset)
+struct Cursor {
+    int s, k0;
+};
+
+// move the cursor forward by `nslabs` K slabs over the flat slab sequence of the tile's GEMM segments
+__device__ __forceinline__ void advance(Cursor& c, int nslabs, const htn_seg* __restrict__ segs, int seg_begin,
+                                        int n_gemm) {
+    while (nslabs > 0 && c.s < n_gemm) {
+        const int K = segs[seg_begin + c.s].k;
+        const int rem = (K - c.k0 + KB - 1) / KB;
+        if (nslabs < rem) {
+            c.k0 += nslabs * KB;
+            nslabs = 0;
+        } else {
+            nslabs -= rem;
+            ++c.s;
+            c.k0 = 0;
+        }
+    }
+}
+
+__device__ __forceinline__ void load_slab(Slab& r, const BufTable& bufs, const htn_tile& T,
+                                          const htn_seg* __restrict__ segs, const Cursor& c, bool valid, int tq) {
+    r.a[0] = r.a[1] = r.b[0] = r.b[1] = make_double2(0.0, 0.0);
+    if (!valid) return;
+    const htn_seg S = segs[T.seg_begin + c.s];
+    const double2* __restrict__ Ap = bufs.p[S.buf_a] + S.a_off;
+    const double2* __restrict__ Bp = bufs.p[S.buf_b] + S.b_off;
+    const int K = S.k;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int r_, kk;
+        if (S.op_a == HTN_OP_N) {       // rows contiguous in memory
+            r_ = tq & 31;
+            kk = (tq >> 5) + 8 * it;
+        } else {                        // k contiguous in memory
+            kk = tq & 15;
+            r_ = (tq >> 4) + 16 * it;
+        }
+        if (r_ < T.m && c.k0 + kk < K) {
+            double2 a;
+            if (S.op_a == HTN_OP_N) a = Ap[(int64_t)(T.row0 + r_) + (int64_t)(c.k0 + kk) * S.lda];
+            else {
+                a = Ap[(int64_t)(c.k0 + kk) + (int64_t)(T.row0 + r_) * S.lda];
+                if (S.op_a == HTN_OP_C) a.y = -a.y;
+            }
+            r.a[it] = make_double2(S.alpha_re * a.x - S.alpha_im * a.y, S.alpha_re * a.y + S.alpha_im * a.x);
+        }
+        int c_, kb;
+        if (S.op_b == HTN_OP_N) {       // k contiguous
+            kb = tq & 15;
+            c_ = (tq >> 4) + 16 * it;
+        } else {                        // columns contiguous
+            c_ = tq & 31;
+            kb = (tq >> 5) + 8 * it;
+        }
+        if (c_ < T.n && c.k0 + kb < K) {
+            double2 b;
+            if (S.op_b == HTN_OP_N) b = Bp[(int64_t)(c.k0 + kb) + (int64_t)(T.col0 + c_) * S.ldb];
+            else {
+                b = Bp[(int64_t)(T.col0 + c_) + (int64_t)(c.k0 + kb) * S.ldb];
+                if (S.op_b == HTN_OP_C) b.y = -b.y;
+            }
+            r.b[it] = b;
+        }
+    }
+}
+
+__device__ __forceinline__ void store_slab(const Slab& r, double* __restrict__ lds, int op_a, int op_b, int tq) {
+    // lds: [A_re | A_im | B_re | B_im] of this quad
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int r_, kk;
+        if (op_a == HTN_OP_N) {
+            r_ = tq & 31;
+            kk = (tq >> 5) + 8 * it;
+        } else {
+            kk = tq & 15;
+            r_ = (tq >> 4) + 16 * it;
+        }
+        lds[0 * SLAB + LDS_AT(kk, r_)] = r.a[it].x;
+        lds[1 * SLAB + LDS_AT(kk, r_)] = r.a[it].y;
+        int c_, kb;
+        if (op_b == HTN_OP_N) {
+            kb = tq & 15;
+            c_ = (tq >> 4) + 16 * it;
+        } else {
+            c_ = tq & 31;
+            kb = (tq >> 5) + 8 * it;
+        }
+        lds[2 * SLAB + LDS_AT(kb, c_)] = r.b[it].x;
+        lds[3 * SLAB + LDS_AT(kb, c_)] = r.b[it].y;
+    }
+}
+
+__global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, const htn_tile* __restrict__ tiles,
+                                                             const htn_seg* __restrict__ segs) {
+    __shared__ double lds_all[NQ * 4 * SLAB];        // 4 quads x (A_re, A_im, B_re, B_im) = 96 KiB
+
+    const htn_tile T = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int q = tid >> 8;               // wave-quad
+    const int tq = tid & 255;             // thread within quad
+    const int lane = tid & 63;
+    const int wave = tq >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double* __restrict__ lds = lds_all + q * 4 * SLAB;
+    const int n_gemm = T.seg_count - T.pad[0];     // GEMM segments first, then pad[0] COPY segments
+
+    d4 acc_re = {0.0, 0.0, 0.0, 0.0};
+    d4 acc_im = {0.0, 0.0, 0.0, 0.0};
+
+    Cursor cur = {0, 0};
+    advance(cur, q, segs, T.seg_begin, n_gemm);      // quad q takes slabs q, q+4, q+8, ... of the flat sequence
+    bool valid = cur.s < n_gemm;
+    Slab regs;
+    load_slab(regs, bufs, T, segs, cur, valid, tq);
+    bool any = n_gemm > 0;
+    while (any) {
+        int op_a = 0, op_b = 0, kleft = 0;
+        if (valid) {
+            const htn_seg& S = segs[T.seg_begin + cur.s];
+            op_a = S.op_a;
+            op_b = S.op_b;
+            kleft = S.k - cur.k0;
+        }
+        store_slab(regs, lds, op_a, op_b, tq);
+        __syncthreads();
+        const bool cur_valid = valid;
+        // advance the cursor and issue the next slab's global loads before the MFMAs
+        if (valid) {
+            advance(cur, NQ, segs, T.seg_begin, n_gemm);
+            valid = cur.s < n_gemm;
+        }
+        load_slab(regs, bufs, T, segs, cur, valid, tq);
+        if (cur_valid) {
+            const int ksteps = kleft >= KB ? KB / 4 : (kleft + 3) >> 2;
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const int kk = ks * 4 + l4;
+                const double b_re = lds[2 * SLAB + LDS_AT(kk, wc * 16 + l15)];   // Aop[i][k] = B[k][c0+i]
+                const double b_im = lds[3 * SLAB + LDS_AT(kk, wc * 16 + l15)];
+                const double a_re = lds[0 * SLAB + LDS_AT(kk, wr * 16 + l15)];   // Bop[k][j] = A[r0+j][k]
+                const double a_im = lds[1 * SLAB + LDS_AT(kk, wr * 16 + l15)];
+                acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_re, acc_re, 0, 0, 0);
+                acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-b_im, a_im, acc_re, 0, 0, 0);
+                acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_im, acc_im, 0, 0, 0);
+                acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_im, a_re, acc_im, 0, 0, 0);
+            }
+        }
+        any = __syncthreads_or(valid ? 1 : 0) != 0;     // also fences LDS reuse
+    }
+    // ---- COPY segments: C += alpha * X tile, spread over the quads (each adds into its partial) ----
+    // this lane's outputs are C[r0 + l15][c0 + l4 + 4 r], r = 0..3
+    const int orow = wr * 16 + l15;
+    for (int s = n_gemm + q; s < T.seg_count; s += NQ) {
+        const htn_seg S = segs[T.seg_begin + s];
+        const double2* __restrict__ Bp = bufs.p[S.buf_b] + S.b_off;
+        if (orow < T.m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ocol = wc * 16 + l4 + 4 * r;
+                if (ocol < T.n) {
+                    const double2 v = Bp[(int64_t)(T.row0 + orow) + (int64_t)(T.col0 + ocol) * S.ldb];
+                    acc_re[r] += S.alpha_re * v.x - S.alpha_im * v.y;
+                    acc_im[r] += S.alpha_re * v.y + S.alpha_im * v.x;
+                }
+            }
+        }
+    }
+    // ---- reduce the 4 partial accumulators through LDS (fixed order => deterministic) ----
+    __syncthreads();
+    double* red = lds_all;                      // [3][256][8] doubles = 48 KiB
+    if (q > 0) {
+        double* dst = red + ((q - 1) * 256 + tq) * 8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dst[r] = acc_re[r];
+            dst[4 + r] = acc_im[r];
+        }
+    }
+    __syncthreads();
+    if (q == 0 && orow < T.m) {
+#pragma unroll
+        for (int p = 0; p < NQ - 1; ++p) {
+            const double* src = red + (p * 256 + tq) * 8;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc_re[r] += src[r];
+                acc_im[r] += src[4 + r];
+            }
+        }
+        double2* __restrict__ Cp = bufs.p[T.buf_c] + T.c_off;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ocol = wc * 16 + l4 + 4 * r;
+            if (ocol < T.n)
+                Cp[(int64_t)(T.row0 + orow) + (int64_t)(T.col0 + ocol) * T.ldc] =
+                    make_double2(acc_re[r], acc_im[r]);
+        }
+    }
+}
+
+extern "C" int htn_grouped_gemm_z(const void* const* bufs_host, const htn_tile* tiles, int32_t n_tiles,
+                                  const htn_seg* segs, void* stream) {
+    if (n_tiles <= 0) return 0;
+    BufTable bt;
+    for (int i = 0; i < HTN_MAX_BUFS; ++i) bt.p[i] = (double2*)bufs_host[i];
+    hipLaunchKernelGGL(k_grouped_gemm_z, dim3(n_tiles), dim3(256 * NQ), 0, (hipStream_t)stream, bt, tiles, segs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

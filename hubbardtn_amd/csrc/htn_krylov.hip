@@ -1,0 +1,392 @@
+// Krylov vector algebra + Lanczos driver (libhubbardtn_hip.so).
+//
+// Stands in for KrylovKit.eigsolve(f, x0, 1, :SR, Lanczos(krylovdim, tol, eager)) as MPSKit calls it
+// on the AC2 effective Hamiltonian (reached from src/HubbardFunctions.jl:1010).
+// All vectors live in HBM; per iteration the host sees only the new tridiagonal coefficients
+// (alpha_j, beta_j) -- one small D2H copy -- and solves the <= krylovdim x krylovdim tridiagonal
+// eigenproblem itself.  The vector kernels are HBM/L2-bandwidth bound (roofline "hbm").
+//
+// Reductions are two-stage with a fixed summation order (per-block partials, then one wave sums the
+// 64 partials with a butterfly), so results are bit-reproducible run to run and rank to rank.
+#include <math.h>
+
+#include <vector>
+
+#include "htn_common.h"
+
+#define DOT_BLOCKS 64         // partial sums per vector; one wave reduces them
+#define DOT_THREADS 256
+#define DOT_CHUNK 8           // vectors handled per pass over the slice of w
+
+// partial[i * DOT_BLOCKS + b] = sum over slice b of conj(V_i) * w
+__global__ __launch_bounds__(DOT_THREADS) void k_dots_partial(const double2* __restrict__ V, int64_t ldv,
+                                                              int nvec, const double2* __restrict__ w,
+                                                              int64_t n, double2* __restrict__ partial) {
+    __shared__ double red[DOT_THREADS / 64][DOT_CHUNK][2];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + DOT_BLOCKS - 1) / DOT_BLOCKS;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < n ? lo + per : n;
+    for (int i0 = 0; i0 < nvec; i0 += DOT_CHUNK) {
+        double sr[DOT_CHUNK], si[DOT_CHUNK];
+#pragma unroll
+        for (int c = 0; c < DOT_CHUNK; ++c) sr[c] = si[c] = 0.0;
+        for (int64_t j = lo + tid; j < hi; j += DOT_THREADS) {
+            const double2 b = w[j];
+#pragma unroll
+            for (int c = 0; c < DOT_CHUNK; ++c) {
+                if (i0 + c < nvec) {
+                    const double2 a = V[(int64_t)(i0 + c) * ldv + j];
+                    sr[c] += a.x * b.x + a.y * b.y;
+                    si[c] += a.x * b.y - a.y * b.x;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < DOT_CHUNK; ++c) {
+            const double r = wave_sum(sr[c]);
+            const double m = wave_sum(si[c]);
+            if ((tid & 63) == 0) {
+                red[tid >> 6][c][0] = r;
+                red[tid >> 6][c][1] = m;
+            }
+        }
+        __syncthreads();
+        if (tid < DOT_CHUNK && i0 + tid < nvec) {
+            double tr = 0.0, ti = 0.0;
+#pragma unroll
+            for (int q = 0; q < DOT_THREADS / 64; ++q) {
+                tr += red[q][tid][0];
+                ti += red[q][tid][1];
+            }
+            partial[(int64_t)(i0 + tid) * DOT_BLOCKS + blockIdx.x] = make_double2(tr, ti);
+        }
+        __syncthreads();
+    }
+}
+
+// one wave per vector: out[i] = sum_b partial[i][b]
+__global__ void k_dots_reduce(const double2* __restrict__ partial, int nvec, double2* __restrict__ out) {
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x;   // 64 threads == DOT_BLOCKS
+    const double2 p = partial[(int64_t)i * DOT_BLOCKS + lane];
+    const double sr = wave_sum(p.x), si = wave_sum(p.y);
+    if (lane == 0) out[i] = make_double2(sr, si);
+}
+
+// fused: c = reduce(partial); w += sign * V c ; norm_partial[b] = |w_new slice|^2 ; block 0 writes c to c_out
+__global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__ w, const double2* __restrict__ V,
+                                                           int64_t ldv, int nvec,
+                                                           const double2* __restrict__ partial,
+                                                           double2* __restrict__ c_out, double sign, int64_t n,
+                                                           double* __restrict__ norm_partial) {
+    __shared__ double cs[64][2];
+    __shared__ double red[DOT_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = wave; i < nvec; i += DOT_THREADS / 64) {
+        const double2 p = partial[(int64_t)i * DOT_BLOCKS + lane];
+        const double sr = wave_sum(p.x), si = wave_sum(p.y);
+        if (lane == 0) {
+            cs[i][0] = sr;
+            cs[i][1] = si;
+            if (blockIdx.x == 0) c_out[i] = make_double2(sr, si);
+        }
+    }
+    __syncthreads();
+    const int64_t per = (n + DOT_BLOCKS - 1) / DOT_BLOCKS;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < n ? lo + per : n;
+    double nn = 0.0;
+    for (int64_t j = lo + tid; j < hi; j += DOT_THREADS) {
+        double sr = 0.0, si = 0.0;
+        for (int i = 0; i < nvec; ++i) {
+            const double2 v = V[(int64_t)i * ldv + j];
+            sr += cs[i][0] * v.x - cs[i][1] * v.y;
+            si += cs[i][0] * v.y + cs[i][1] * v.x;
+        }
+        double2 x = w[j];
+        x.x += sign * sr;
+        x.y += sign * si;
+        w[j] = x;
+        nn += x.x * x.x + x.y * x.y;
+    }
+    nn = wave_sum(nn);
+    if (lane == 0) red[wave] = nn;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < DOT_THREADS / 64; ++q) t += red[q];
+        norm_partial[blockIdx.x] = t;
+    }
+}
+
+// dst = src / sqrt(sum norm_partial); block 0 writes the squared norm to nrm2_out (may be null)
+__global__ __launch_bounds__(DOT_THREADS) void k_scale_by_norm(double2* __restrict__ dst, const double2* __restrict__ src,
+                                                               const double* __restrict__ norm_partial, int64_t n,
+                                                               double* __restrict__ nrm2_out) {
+    __shared__ double s_inv;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const double t = wave_sum(norm_partial[tid]);
+        if (tid == 0) {
+            s_inv = t > 0.0 ? 1.0 / sqrt(t) : 0.0;
+            if (blockIdx.x == 0 && nrm2_out) nrm2_out[0] = t;
+        }
+    }
+    __syncthreads();
+    const double s = s_inv;
+    for (int64_t j = (int64_t)blockIdx.x * DOT_THREADS + tid; j < n; j += (int64_t)gridDim.x * DOT_THREADS) {
+        const double2 v = src[j];
+        dst[j] = make_double2(v.x * s, v.y * s);
+    }
+}
+
+// |w|^2 partials only (start-vector normalisation)
+__global__ __launch_bounds__(DOT_THREADS) void k_norm_partial(const double2* __restrict__ w, int64_t n,
+                                                              double* __restrict__ norm_partial) {
+    __shared__ double red[DOT_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + DOT_BLOCKS - 1) / DOT_BLOCKS;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < n ? lo + per : n;
+    double nn = 0.0;
+    for (int64_t j = lo + tid; j < hi; j += DOT_THREADS) {
+        const double2 x = w[j];
+        nn += x.x * x.x + x.y * x.y;
+    }
+    nn = wave_sum(nn);
+    if ((tid & 63) == 0) red[tid >> 6] = nn;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int q = 0; q < DOT_THREADS / 64; ++q) t += red[q];
+        norm_partial[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_axpys(double2* __restrict__ w, const double2* __restrict__ V,
+                                               int64_t ldv, int nvec, const double2* __restrict__ coef,
+                                               double sign, int64_t n) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        double sr = 0.0, si = 0.0;
+        for (int i = 0; i < nvec; ++i) {
+            const double2 c = coef[i];
+            const double2 v = V[(int64_t)i * ldv + j];
+            sr += c.x * v.x - c.y * v.y;
+            si += c.x * v.y + c.y * v.x;
+        }
+        double2 x = w[j];
+        x.x += sign * sr;
+        x.y += sign * si;
+        w[j] = x;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scale_inv_sqrt(double2* __restrict__ dst, const double2* __restrict__ src,
+                                                        const double2* __restrict__ nrm2, int64_t n) {
+    const double s = 1.0 / sqrt(nrm2[0].x);
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const double2 v = src[j];
+        dst[j] = make_double2(v.x * s, v.y * s);
+    }
+}
+
+static inline int grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
+extern "C" int64_t htn_dots_scratch_elems(int32_t nvec) { return (int64_t)nvec * DOT_BLOCKS; }
+
+extern "C" int htn_dots_z(const void* V, int64_t ldv, int32_t nvec, const void* w, int64_t n, void* out,
+                          void* scratch, void* stream) {
+    if (nvec <= 0) return 0;
+    if (nvec > 64) return fail_msg("htn_dots_z: nvec > 64");
+    hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, (hipStream_t)stream,
+                       (const double2*)V, ldv, nvec, (const double2*)w, n, (double2*)scratch);
+    hipLaunchKernelGGL(k_dots_reduce, dim3(nvec), dim3(64), 0, (hipStream_t)stream, (const double2*)scratch,
+                       nvec, (double2*)out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int htn_axpys_z(void* w, const void* V, int64_t ldv, int32_t nvec, const void* coef, double sign,
+                           int64_t n, void* stream) {
+    if (nvec <= 0 || n <= 0) return 0;
+    hipLaunchKernelGGL(k_axpys, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (double2*)w, (const double2*)V,
+                       ldv, nvec, (const double2*)coef, sign, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int htn_scale_inv_sqrt_z(void* dst, const void* src, const void* nrm2, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_scale_inv_sqrt, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (double2*)dst,
+                       (const double2*)src, (const double2*)nrm2, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// host side of the Lanczos driver
+// ----------------------------------------------------------------------------------------------
+// lowest eigenpair of the symmetric tridiagonal (alpha, beta) by cyclic Jacobi on the dense k x k
+// matrix (k <= 64: microseconds on the host, unconditionally convergent, no LAPACK dependency)
+static void tridiag_lowest(const std::vector<double>& alpha, const std::vector<double>& beta, double* eig,
+                           std::vector<double>& vec) {
+    const int k = (int)alpha.size();
+    std::vector<double> A(k * k, 0.0), Q(k * k, 0.0);
+    for (int i = 0; i < k; ++i) {
+        A[i * k + i] = alpha[i];
+        Q[i * k + i] = 1.0;
+        if (i + 1 < k) A[i * k + i + 1] = A[(i + 1) * k + i] = beta[i];
+    }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < k; ++i) {
+            diag += A[i * k + i] * A[i * k + i];
+            for (int j = i + 1; j < k; ++j) off += A[i * k + j] * A[i * k + j];
+        }
+        if (off <= 1e-32 * (diag + off)) break;
+        for (int p = 0; p < k - 1; ++p)
+            for (int q = p + 1; q < k; ++q) {
+                const double apq = A[p * k + q];
+                if (apq == 0.0) continue;
+                const double zeta = (A[q * k + q] - A[p * k + p]) / (2.0 * apq);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int r = 0; r < k; ++r) {
+                    const double arp = A[r * k + p], arq = A[r * k + q];
+                    A[r * k + p] = c * arp - s * arq;
+                    A[r * k + q] = s * arp + c * arq;
+                }
+                for (int r = 0; r < k; ++r) {
+                    const double apr = A[p * k + r], aqr = A[q * k + r];
+                    A[p * k + r] = c * apr - s * aqr;
+                    A[q * k + r] = s * apr + c * aqr;
+                }
+                for (int r = 0; r < k; ++r) {
+                    const double qrp = Q[r * k + p], qrq = Q[r * k + q];
+                    Q[r * k + p] = c * qrp - s * qrq;
+                    Q[r * k + q] = s * qrp + c * qrq;
+                }
+            }
+    }
+    int best = 0;
+    for (int i = 1; i < k; ++i)
+        if (A[i * k + i] < A[best * k + best]) best = i;
+    *eig = A[best * k + best];
+    vec.resize(k);
+    for (int r = 0; r < k; ++r) vec[r] = Q[r * k + best];
+}
+
+extern "C" int64_t htn_lanczos_scratch_elems(int32_t krylovdim) {
+    // partial sums (krylovdim+1 vectors) + c1 + c2 + y (each krylovdim+1) + norm partials / nrm2 (as doubles)
+    return (int64_t)(krylovdim + 1) * DOT_BLOCKS + 3 * (krylovdim + 1) + DOT_BLOCKS + 8;
+}
+
+extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, int32_t x_slot, int32_t y_slot,
+                             void* Vv, int64_t n, int32_t krylovdim, double tol, int32_t max_restart,
+                             void* scratch, int32_t zero_y, htn_exchange_fn exchange, void* user,
+                             double* eig_host, int32_t* n_matvec_host, double* residual_host,
+                             double* matvec_ms_host, void* stream_v) {
+    hipStream_t st = (hipStream_t)stream_v;
+    const int kd = krylovdim;
+    if (kd < 2 || kd > 63) return fail_msg("htn_lanczos_z: krylovdim must be in 2..63");
+    double2* V = (double2*)Vv;
+    double2* partial = (double2*)scratch;
+    double2* c1 = partial + (int64_t)(kd + 1) * DOT_BLOCKS;
+    double2* c2 = c1 + (kd + 1);
+    double2* ycoef = c2 + (kd + 1);
+    double* norm_partial = (double*)(ycoef + (kd + 1));
+    double* nrm2 = norm_partial + DOT_BLOCKS;
+
+    static thread_local double2* h_c = nullptr;     // pinned staging for the per-iteration D2H
+    if (!h_c) HIP_TRY(hipHostMalloc((void**)&h_c, sizeof(double2) * (2 * 64 + 2 + 64)));
+    double2* h_c1 = h_c;
+    double2* h_c2 = h_c + 64;
+    double* h_n = (double*)(h_c + 128);
+    double2* h_y = h_c + 130;
+
+    auto matvec = [&](double2* x, double2* y) -> int {
+        if (zero_y) HIP_TRY(hipMemsetAsync(y, 0, sizeof(double2) * n, st));
+        for (int s = 0; s < n_stages; ++s) {
+            const void* bufs[HTN_MAX_BUFS];
+            for (int b = 0; b < HTN_MAX_BUFS; ++b) bufs[b] = stages[s].bufs[b];
+            bufs[x_slot] = x;
+            bufs[y_slot] = y;
+            if (htn_grouped_gemm_z(bufs, stages[s].tiles, stages[s].n_tiles, stages[s].segs, st)) return 1;
+        }
+        if (exchange) exchange(y, n, user);
+        return 0;
+    };
+
+    // normalise the start vector
+    hipLaunchKernelGGL(k_norm_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, norm_partial);
+    hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, V, V, norm_partial, n,
+                       (double*)nullptr);
+    static thread_local hipEvent_t ev0 = nullptr, ev1 = nullptr;   // optional matvec timing (bench roofline)
+    if (matvec_ms_host && !ev0) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+    }
+    double mv_ms = 0.0;
+    int nmv = 0;
+    double theta = 0.0, res = 0.0, beta = 0.0;
+    std::vector<double> y;
+    for (int restart = 0; restart <= max_restart; ++restart) {
+        std::vector<double> alphas, betas;
+        for (int j = 0; j < kd; ++j) {
+            double2* vj = V + (int64_t)j * n;
+            double2* w = V + (int64_t)(j + 1) * n;
+            if (matvec_ms_host) HIP_TRY(hipEventRecord(ev0, st));
+            if (matvec(vj, w)) return 1;
+            if (matvec_ms_host) HIP_TRY(hipEventRecord(ev1, st));
+            ++nmv;
+            // two passes of classical Gram-Schmidt against ALL Krylov vectors (full reorthogonalisation)
+            hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, j + 1, w, n, partial);
+            hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial, c1,
+                               -1.0, n, norm_partial);
+            hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, j + 1, w, n, partial);
+            hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial, c2,
+                               -1.0, n, norm_partial);
+            // v_{j+1} = w / |w| ; also leaves |w|^2 in nrm2
+            hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, w, w, norm_partial, n, nrm2);
+            HIP_TRY(hipMemcpyAsync(h_c1 + j, c1 + j, sizeof(double2), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_c2 + j, c2 + j, sizeof(double2), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_n, nrm2, sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (matvec_ms_host) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+                mv_ms += ms;
+            }
+            const double alpha = h_c1[j].x + h_c2[j].x;
+            beta = sqrt(h_n[0] > 0.0 ? h_n[0] : 0.0);
+            alphas.push_back(alpha);
+            tridiag_lowest(alphas, betas, &theta, y);
+            res = fabs(beta * y.back());
+            if (res < tol || beta < 1e-14 || j == kd - 1) break;
+            betas.push_back(beta);
+        }
+        // x = sum_i y_i V_i  -> scratch row kd+1, normalised into row 0
+        const int k = (int)y.size();
+        for (int i = 0; i < k; ++i) h_y[i] = make_double2(y[i], 0.0);
+        HIP_TRY(hipMemcpyAsync(ycoef, h_y, sizeof(double2) * k, hipMemcpyHostToDevice, st));
+        double2* xrow = V + (int64_t)(kd + 1) * n;
+        HIP_TRY(hipMemsetAsync(xrow, 0, sizeof(double2) * n, st));
+        hipLaunchKernelGGL(k_axpys, dim3(grid_for(n)), dim3(256), 0, st, xrow, V, n, k, ycoef, 1.0, n);
+        hipLaunchKernelGGL(k_norm_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, xrow, n, norm_partial);
+        hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, V, xrow, norm_partial, n,
+                           (double*)nullptr);
+        HIP_TRY(hipStreamSynchronize(st));      // h_y is reused by the next restart / call
+        if (res < tol || beta < 1e-14) break;
+    }
+    HIP_TRY(hipGetLastError());
+    *eig_host = theta;
+    *n_matvec_host = nmv;
+    *residual_host = res;
+    if (matvec_ms_host) *matvec_ms_host = mv_ms;
+    return 0;
+}

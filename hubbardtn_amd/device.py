@@ -109,6 +109,37 @@ class HipOps:
         abi.check(self.lib, self.lib.htn_scale_inv_sqrt_z(self._p(dst), self._p(src), self._p(nrm2), n,
                                                           self._stream()), "htn_scale_inv_sqrt_z")
 
+    def lanczos(self, stages, x_slot, y_slot, V, n, krylovdim, tol, max_restart, zero_y=False, exchange=None):
+        """lowest eigenpair of the map defined by `stages` = [(bufs, dev_tasks), ...]; V[0:n] start -> result.
+        exchange(y_tensor) is called after every matvec has been enqueued (multi-GPU all-reduce hook).
+        Returns (eigenvalue, n_matvec, residual)."""
+        arr = (abi.GemmLaunch * len(stages))()
+        keep = []
+        for k, (bufs, (tiles, ntiles, segs)) in enumerate(stages):
+            for b in range(abi.HTN_MAX_BUFS):
+                arr[k].bufs[b] = 0 if bufs[b] is None else bufs[b].data_ptr()
+            arr[k].tiles, arr[k].segs, arr[k].n_tiles = tiles.data_ptr(), segs.data_ptr(), ntiles
+            keep.append((bufs, tiles, segs))
+        need = self.lib.htn_lanczos_scratch_elems(krylovdim)
+        if getattr(self, "_lan_scratch", None) is None or self._lan_scratch.numel() < need:
+            self._lan_scratch = self.empty_z(need)
+        base = V.data_ptr()
+
+        def _cb(y_ptr, nn, user):
+            off = (y_ptr - base) // 16
+            exchange(V[off:off + nn])
+        cb = abi.EXCHANGE_FN(_cb) if exchange is not None else abi.EXCHANGE_FN()
+        eig, nmv, res, ms = C.c_double(0.0), C.c_int32(0), C.c_double(0.0), C.c_double(0.0)
+        timed = self.event_log is not None
+        abi.check(self.lib, self.lib.htn_lanczos_z(arr, len(stages), x_slot, y_slot, self._p(V), n, krylovdim,
+                                                   float(tol), max_restart, self._p(self._lan_scratch),
+                                                   1 if zero_y else 0, cb, None, C.byref(eig), C.byref(nmv),
+                                                   C.byref(res), C.byref(ms) if timed else None, self._stream()),
+                  "htn_lanczos_z")
+        if timed:
+            self.event_log.append(("matvec_ms", ms.value, nmv.value))
+        return eig.value, nmv.value, res.value
+
     def jacobi_svd(self, G, Vj, S, desc_dev, nblocks, max_m, max_sweeps, tol, info):
         abi.check(self.lib, self.lib.htn_jacobi_svd_z(self._p(G), self._p(Vj), self._p(S), self._p(desc_dev),
                                                       nblocks, max_m, max_sweeps, float(tol), self._p(info),

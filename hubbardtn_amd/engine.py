@@ -45,15 +45,6 @@ class BondStats:
     t_env: float = 0.0
 
 
-def _tridiag_lowest(alphas, betas):
-    k = len(alphas)
-    T = np.diag(np.asarray(alphas, dtype=float))
-    for i in range(k - 1):
-        T[i, i + 1] = T[i + 1, i] = betas[i]
-    w, v = np.linalg.eigh(T)
-    return float(w[0]), v[:, 0]
-
-
 class DMRG2:
     """finite two-site DMRG on reduced SU(2) x U(1) tensors.
 
@@ -162,73 +153,23 @@ class DMRG2:
 
     # ---- effective Hamiltonian --------------------------------------------------------------------
     def _make_apply(self, i, tl):
+        """stage list of the H_eff apply on bond (i, i+1): [(buffer table, device task list), ...]"""
         ops = self.ops
         tz, ty, zsize, nterms = pl.plan_apply(tl, self.Llay[i], self.Rlay[i + 2], self.mpo[i], self.mpo[i + 1])
+        flops = ty.flops + (tz.flops if tz is not None else 0)
+        ntiles = ty.ntiles + (tz.ntiles if tz else 0)
+        nsegs = ty.nsegs + (tz.nsegs if tz else 0)
         if self.shard is not None:
             rank, world, _ = self.shard
             ty = _shard_tasks(ty, rank, world)
-        dz = ops.upload_tasks(tz) if tz is not None else None
-        dy = ops.upload_tasks(ty)
         z = ops.empty_z(max(zsize, 1))
         Lb, Rb = self.Lbuf[i], self.Rbuf[i + 2]
-
-        def apply(x, y):
-            if self.shard is not None:
-                ops.zero(y)
-            if dz is not None:
-                ops.grouped_gemm(self._bufs(x=x, l=Lb, z=z), dz, tag="apply_z", flops=tz.flops)
-            ops.grouped_gemm(self._bufs(x=x, y=y, l=Lb, r=Rb, z=z), dy, tag="apply", flops=ty.flops)
-            if self.shard is not None:
-                self.shard[2](y)
-        flops = ty.flops + (tz.flops if tz is not None else 0)
+        stages = []
+        if tz is not None:
+            stages.append((self._bufs(l=Lb, z=z), ops.upload_tasks(tz)))
+        stages.append((self._bufs(l=Lb, r=Rb, z=z), ops.upload_tasks(ty)))
         nbytes = 16 * (2 * tl.size + self.Llay[i].size + self.Rlay[i + 2].size)
-        return apply, flops, nbytes, ty.ntiles + (tz.ntiles if tz else 0), ty.nsegs + (tz.nsegs if tz else 0)
-
-    def _lanczos(self, apply, V, n, scal):
-        """lowest eigenpair; V: flat Krylov workspace with V[0:n] = normalised start vector.
-        Returns (eigenvalue, index of buffer row holding x, n_matvec, residual)."""
-        ops = self.ops
-        kd = self.krylovdim
-        nmv = 0
-        res, theta = None, None
-        for restart in range(self.maxrestart + 1):
-            alphas, betas = [], []
-            y = None
-            for j in range(kd):
-                vj = V[j * n:(j + 1) * n]
-                w = V[(j + 1) * n:(j + 2) * n]
-                apply(vj, w)
-                nmv += 1
-                c1 = scal[0:j + 1]
-                c2 = scal[kd + 1:kd + 2 + j]
-                ops.dots(V, n, j + 1, w, n, c1)
-                ops.axpys(w, V, n, j + 1, c1, -1.0, n)
-                ops.dots(V, n, j + 1, w, n, c2)
-                ops.axpys(w, V, n, j + 1, c2, -1.0, n)
-                nr = scal[2 * kd + 2:2 * kd + 3]
-                ops.dots(w, n, 1, w, n, nr)
-                h = ops.to_host(scal)
-                alpha = float(h[j].real + h[kd + 1 + j].real)
-                beta = float(np.sqrt(max(h[2 * kd + 2].real, 0.0)))
-                alphas.append(alpha)
-                theta, y = _tridiag_lowest(alphas, betas)
-                res = abs(beta * y[-1])
-                if res < self.lanczos_tol or beta < 1e-14 or j == kd - 1:
-                    break
-                betas.append(beta)
-                ops.scale_inv_sqrt(w, w, nr, n)
-            k = len(y)
-            # x = sum_i y_i V_i  -> store in row kd+1 (scratch row), then move to row 0
-            xrow = V[(kd + 1) * n:(kd + 2) * n]
-            ops.zero(xrow)
-            coef = ops.to_device(np.asarray(y, dtype=np.complex128))
-            ops.axpys(xrow, V, n, k, coef, 1.0, n)
-            nr = scal[2 * kd + 2:2 * kd + 3]
-            ops.dots(xrow, n, 1, xrow, n, nr)
-            ops.scale_inv_sqrt(V[0:n], xrow, nr, n)
-            if res < self.lanczos_tol or beta < 1e-14:
-                break
-        return theta, nmv, res
+        return stages, flops, nbytes, ntiles, nsegs
 
     # ---- one bond ---------------------------------------------------------------------------------
     def update_bond(self, i, direction, placement):
@@ -244,18 +185,16 @@ class DMRG2:
         mode = lay1.kind + lay2.kind
         assert mode in ("RR", "LL", "LR"), mode
         V = ops.empty_z((kd + 2) * n)
-        scal = ops.zeros_z(2 * kd + 4)
-        # theta -> V[0]
+        # theta -> V[0] (the Lanczos driver normalises it)
         tth = pl.plan_theta(mode, lay1, lay2, tl)
         ops.grouped_gemm(self._bufs(s1=self.site_buf[i], s2=self.site_buf[i + 1], y=V[0:n]), ops.upload_tasks(tth))
-        nr = scal[2 * kd + 2:2 * kd + 3]
-        ops.dots(V[0:n], n, 1, V[0:n], n, nr)
-        ops.scale_inv_sqrt(V[0:n], V[0:n], nr, n)
-        apply, aflops, abytes, ntiles, nsegs = self._make_apply(i, tl)
+        stages, aflops, abytes, ntiles, nsegs = self._make_apply(i, tl)
         if self.profile:
             ops.sync()
         t_plan = time.perf_counter() - t0
-        E, nmv, res = self._lanczos(apply, V, n, scal)
+        E, nmv, res = ops.lanczos(stages, BUF_X, BUF_Y, V, n, kd, self.lanczos_tol, self.maxrestart,
+                                  zero_y=self.shard is not None,
+                                  exchange=self.shard[2] if self.shard is not None else None)
         if self.profile:
             ops.sync()
         t_lan = time.perf_counter() - t0 - t_plan

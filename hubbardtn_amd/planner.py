@@ -281,6 +281,8 @@ class TaskList:
             for sg in b["segs"]:
                 merged[sg[:10]] = merged.get(sg[:10], 0.0) + sg[10]
             seglist = [(k_, a_) for k_, a_ in merged.items() if a_ != 0.0]
+            seglist.sort(key=lambda t: t[0][0])          # GEMM segments first, COPY segments last
+            ncopy = sum(1 for k_, _ in seglist if k_[0] == SEG_COPY)
             start = pos
             ksum = 0
             for (typ, buf_a, a_off, lda, op_a, buf_b, b_off, ldb, op_b, k), alpha in seglist:
@@ -295,12 +297,12 @@ class TaskList:
             for r0 in range(0, b["m"], HTN_TILE):
                 for c0 in range(0, b["n"], HTN_TILE):
                     tm, tn = min(HTN_TILE, b["m"] - r0), min(HTN_TILE, b["n"] - c0)
-                    tiles.append((tm * tn * (ksum + 1), b["off"], b["buf"], b["ld"], tm, tn, r0, c0, start, cnt))
+                    tiles.append((tm * tn * (ksum + 1), b["off"], b["buf"], b["ld"], tm, tn, r0, c0, start, cnt, ncopy))
         tiles.sort(key=lambda t: -t[0])      # longest first: hardware dispatch order = LPT schedule
         tarr = np.zeros(max(len(tiles), 1), dtype=TILE_DT)
         for i, t in enumerate(tiles):
             (_, tarr[i]["c_off"], tarr[i]["buf_c"], tarr[i]["ldc"], tarr[i]["m"], tarr[i]["n"],
-             tarr[i]["row0"], tarr[i]["col0"], tarr[i]["seg_begin"], tarr[i]["seg_count"]) = t
+             tarr[i]["row0"], tarr[i]["col0"], tarr[i]["seg_begin"], tarr[i]["seg_count"], tarr[i]["pad0"]) = t
         return Tasks(tarr, len(tiles), segs[:max(pos, 1)], pos, flops)
 
 

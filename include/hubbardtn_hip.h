@@ -39,7 +39,8 @@ extern "C" {
 #define HTN_SEG_COPY 1           /* C += alpha * B  (B is m x n)     */
 
 /* One output tile (<= 32 x 32) of an output block.  The tile owns segs[seg_begin .. +seg_count)
- * and is WRITTEN (not accumulated): a tile with no segments stores zeros. */
+ * and is WRITTEN (not accumulated): a tile with no segments stores zeros.  Within that range all
+ * GEMM segments come first and the last pad[0] entries are the COPY segments. */
 typedef struct {
     int64_t c_off;      /* element offset of the BLOCK origin inside bufs[buf_c]   */
     int32_t buf_c;      /* index into the buffer table                              */
@@ -72,8 +73,7 @@ int htn_device_init(int device, char* name_host, int* cu_count_host);
  * Stands in for: TensorKit block mul! (BLAS zgemm per coupled sector) + the TensorOperations /
  * Strided permutes around it, as executed inside MPSKit's AC2 effective-Hamiltonian apply and
  * environment transfers (reached from src/HubbardFunctions.jl:1010).
- * bufs_host: HTN_MAX_BUFS device base pointers (unused entries may be NULL).
- * If tile_ms_dev != NULL it must hold n_tiles floats and is left untouched (reserved). */
+ * bufs_host: HTN_MAX_BUFS device base pointers (unused entries may be NULL). */
 int htn_grouped_gemm_z(const void* const* bufs_host, const htn_tile* tiles, int32_t n_tiles,
                        const htn_seg* segs, void* stream);
 
@@ -90,6 +90,34 @@ int htn_axpys_z(void* w, const void* V, int64_t ldv, int32_t nvec, const void* c
                 double sign, int64_t n, void* stream);
 /* dst[j] = src[j] / sqrt(Re(nrm2[0]))  (nrm2 on device; dst may alias src) */
 int htn_scale_inv_sqrt_z(void* dst, const void* src, const void* nrm2, int64_t n, void* stream);
+
+/* Device-resident Lanczos: lowest eigenpair of the Hermitian map y = H_eff x given as a short sequence of
+ * grouped-GEMM launches (stage list; the buffer-table entries x_slot / y_slot are replaced by the current
+ * Krylov vector / the output vector for every matvec).
+ * Stands in for: KrylovKit.eigsolve(H_eff, x0, 1, :SR, Lanczos(krylovdim, tol, eager=true)) as called by
+ * MPSKit's two-site update (reached from src/HubbardFunctions.jl:1010): orthonormal Krylov
+ * basis kept in full, explicit two-pass reorthogonalisation, tridiagonal problem solved after every expansion,
+ * stop when |beta_j y_j| < tol, restart from the Ritz vector at krylovdim.
+ * V: (krylovdim + 2) * n complex128; on entry V[0:n] = start vector, on exit V[0:n] = normalised Ritz vector.
+ * exchange (may be NULL): called on the host after each matvec has been ENQUEUED, with the device pointer of y;
+ * the multi-GPU host uses it to enqueue an RCCL all-reduce of y on the same stream (zero_y = 1 then clears y
+ * before the local tiles are written).  The call synchronises the stream once per iteration (it needs
+ * alpha_j, beta_j on the host). */
+typedef struct {
+    const void* bufs[HTN_MAX_BUFS];
+    const htn_tile* tiles;
+    const htn_seg* segs;
+    int32_t n_tiles;
+    int32_t pad;
+} htn_gemm_launch;
+typedef void (*htn_exchange_fn)(void* y_dev, int64_t n, void* user);
+int64_t htn_lanczos_scratch_elems(int32_t krylovdim);
+int htn_lanczos_z(const htn_gemm_launch* stages_host, int32_t n_stages, int32_t x_slot, int32_t y_slot,
+                  void* V, int64_t n, int32_t krylovdim, double tol, int32_t max_restart, void* scratch,
+                  int32_t zero_y, htn_exchange_fn exchange, void* user,
+                  double* eig_host, int32_t* n_matvec_host, double* residual_host,
+                  double* matvec_ms_host /* NULL, or receives the HIP-event time of all matvec launches */,
+                  void* stream);
 
 /* Batched one-sided Jacobi SVD of the coupled-sector blocks of a two-site tensor.
  * Stands in for: TensorKit tsvd!(t; alg=SVD()) -> LAPACK zgesvd per block (SURVEY.md 8a a9,

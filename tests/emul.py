@@ -90,6 +90,49 @@ class NumpyOps:
     def scale_inv_sqrt(self, dst, src, nrm2, n):
         dst[:n] = src[:n] / np.sqrt(nrm2[0].real)
 
+    def lanczos(self, stages, x_slot, y_slot, V, n, krylovdim, tol, max_restart, zero_y=False, exchange=None):
+        """numpy statement of htn_lanczos_z (same algorithm: CGS2 full reorthogonalisation, eager stop)"""
+        def matvec(x, y):
+            if zero_y:
+                y[...] = 0
+            for bufs, tasks in stages:
+                b = list(bufs)
+                b[x_slot], b[y_slot] = x, y
+                self.grouped_gemm(b, tasks)
+            if exchange is not None:
+                exchange(y)
+        kd = krylovdim
+        V[0:n] /= np.linalg.norm(V[0:n])
+        nmv, theta, res, beta = 0, 0.0, 0.0, 0.0
+        for restart in range(max_restart + 1):
+            alphas, betas = [], []
+            for j in range(kd):
+                w = V[(j + 1) * n:(j + 2) * n]
+                matvec(V[j * n:(j + 1) * n], w)
+                nmv += 1
+                Vm = V[:(j + 1) * n].reshape(j + 1, n)
+                c1 = Vm.conj() @ w
+                w -= Vm.T @ c1
+                c2 = Vm.conj() @ w
+                w -= Vm.T @ c2
+                beta = float(np.linalg.norm(w))
+                alphas.append(float((c1[j] + c2[j]).real))
+                T = np.diag(alphas) + np.diag(betas, 1) + np.diag(betas, -1)
+                ev, evec = np.linalg.eigh(T)
+                theta, y = float(ev[0]), evec[:, 0]
+                res = abs(beta * y[-1])
+                if beta > 0:
+                    w /= beta
+                if res < tol or beta < 1e-14 or j == kd - 1:
+                    break
+                betas.append(beta)
+            k = len(y)
+            x = V[:k * n].reshape(k, n).T @ y.astype(np.complex128)
+            V[0:n] = x / np.linalg.norm(x)
+            if res < tol or beta < 1e-14:
+                break
+        return theta, nmv, res
+
     def jacobi_svd(self, G, Vj, S, desc, nblocks, max_m, max_sweeps, tol, info):
         for b in range(nblocks):
             d = desc[b]

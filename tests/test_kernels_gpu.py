@@ -159,3 +159,28 @@ def test_batched_copy_matches_numpy(hip_ops):
     hip_ops.batched_copy(dst, hip_ops.to_device(src), hip_ops.to_device(idx), hip_ops.to_device(scl),
                          hip_ops.to_device(items), len(items), 0.7)
     assert np.abs(hip_ops.to_host(dst) - ref).max() < 1e-14
+
+
+def test_lanczos_driver_matches_dense_eigh(hip_ops):
+    """htn_lanczos_z on a Hermitian map given as one grouped-GEMM stage (y = H x, H dense 200x200 here,
+    x stored as a 200 x 3 block so the stage exercises tiles + segments) vs numpy eigh"""
+    rng = np.random.default_rng(6)
+    m, nc = 200, 3
+    H = _rand_z(rng, m * m).reshape(m, m)
+    H = H + H.conj().T
+    tl = TaskList()
+    tl.block(0, 1, 0, m, nc, m)
+    tl.gemm(0, 2, 0, m, abi.OP_N, 0, 0, m, abi.OP_N, m, 1.0)
+    tasks = tl.finalize()
+    n = m * nc
+    kd = 30
+    V = hip_ops.zeros_z((kd + 2) * n)
+    x0 = _rand_z(rng, n)
+    V[0:n] = hip_ops.to_device(x0)
+    stages = [([None, None, hip_ops.to_device(H.T.reshape(-1).copy())] + [None] * 5, hip_ops.upload_tasks(tasks))]
+    eig, nmv, res = hip_ops.lanczos(stages, 0, 1, V, n, kd, 1e-10, 20)
+    ref = np.linalg.eigvalsh(H)[0]
+    assert abs(eig - ref) <= 1e-9 * abs(ref)
+    x = hip_ops.to_host(V[0:n]).reshape(nc, m).T
+    assert abs(np.linalg.norm(x) - 1) < 1e-12
+    assert np.linalg.norm(H @ x - eig * x) < 1e-6
