@@ -25,12 +25,14 @@ TILE_DT = np.dtype([("c_off", "<i8"), ("buf_c", "<i4"), ("ldc", "<i4"), ("m", "<
 SEG_DT = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("buf_a", "<i4"), ("buf_b", "<i4"),
                    ("lda", "<i4"), ("ldb", "<i4"), ("k", "<i4"), ("op_a", "<i4"), ("op_b", "<i4"),
                    ("type", "<i4"), ("alpha_re", "<f8"), ("alpha_im", "<f8")], align=False)
-SVD_DT = np.dtype([("g_off", "<i8"), ("v_off", "<i8"), ("s_off", "<i8"), ("m", "<i4"), ("n", "<i4")],
-                  align=False)
+SVD_DT = np.dtype([("g_off", "<i8"), ("v_off", "<i8"), ("s_off", "<i8"), ("m", "<i4"), ("n", "<i4"),
+                   ("flags", "<i4"), ("pad", "<i4")], align=False)
+SVD_ACCUMULATE = 1
+SVD_QRCP = 2
 COPY_DT = np.dtype([("dst_off", "<i8"), ("src_off", "<i8"), ("idx_off", "<i8"), ("scl_off", "<i8"),
                     ("rows", "<i4"), ("cols", "<i4"), ("ldd", "<i4"), ("lds", "<i4"), ("op", "<i4"),
                     ("gather_dim", "<i4"), ("scale_dim", "<i4"), ("inv_norm", "<i4")], align=False)
-assert TILE_DT.itemsize == 48 and SEG_DT.itemsize == 64 and SVD_DT.itemsize == 32 and COPY_DT.itemsize == 64
+assert TILE_DT.itemsize == 48 and SEG_DT.itemsize == 64 and SVD_DT.itemsize == 40 and COPY_DT.itemsize == 64
 
 EXPORTS = ["htn_last_error", "htn_abi_version", "htn_device_init", "htn_grouped_gemm_z",
            "htn_dots_scratch_elems", "htn_dots_z", "htn_axpys_z", "htn_scale_inv_sqrt_z",

@@ -14,11 +14,24 @@
 
 #include "htn_common.h"
 
-#define DOT_BLOCKS 64         // partial sums per vector; one wave reduces them
+#define DOT_BLOCKS 128        // partial sums per vector (2 per lane of the reducing wave)
 #define DOT_THREADS 256
-#define DOT_CHUNK 8           // vectors handled per pass over the slice of w
+#define DOT_CHUNK 32          // vectors handled per pass over the slice of w (krylovdim + 1 <= 31 by default)
 
-// partial[i * DOT_BLOCKS + b] = sum over slice b of conj(V_i) * w
+// sum of the DOT_BLOCKS partials of one vector by one wave, fixed order
+__device__ __forceinline__ double2 reduce_partials(const double2* __restrict__ p, int lane) {
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int b = 0; b < DOT_BLOCKS / 64; ++b) {
+        const double2 v = p[lane + 64 * b];
+        sr += v.x;
+        si += v.y;
+    }
+    return make_double2(wave_sum(sr), wave_sum(si));
+}
+
+// partial[i * DOT_BLOCKS + b] = sum over slice b of conj(V_i) * w.  One pass over the slice for up to 32
+// vectors: every thread issues all its loads back to back (latency, not bandwidth, bounds this kernel).
 __global__ __launch_bounds__(DOT_THREADS) void k_dots_partial(const double2* __restrict__ V, int64_t ldv,
                                                               int nvec, const double2* __restrict__ w,
                                                               int64_t n, double2* __restrict__ partial) {
@@ -44,11 +57,13 @@ __global__ __launch_bounds__(DOT_THREADS) void k_dots_partial(const double2* __r
         }
 #pragma unroll
         for (int c = 0; c < DOT_CHUNK; ++c) {
-            const double r = wave_sum(sr[c]);
-            const double m = wave_sum(si[c]);
-            if ((tid & 63) == 0) {
-                red[tid >> 6][c][0] = r;
-                red[tid >> 6][c][1] = m;
+            if (i0 + c < nvec) {
+                const double r = wave_sum(sr[c]);
+                const double m = wave_sum(si[c]);
+                if ((tid & 63) == 0) {
+                    red[tid >> 6][c][0] = r;
+                    red[tid >> 6][c][1] = m;
+                }
             }
         }
         __syncthreads();
@@ -68,13 +83,12 @@ __global__ __launch_bounds__(DOT_THREADS) void k_dots_partial(const double2* __r
 // one wave per vector: out[i] = sum_b partial[i][b]
 __global__ void k_dots_reduce(const double2* __restrict__ partial, int nvec, double2* __restrict__ out) {
     const int i = blockIdx.x;
-    const int lane = threadIdx.x;   // 64 threads == DOT_BLOCKS
-    const double2 p = partial[(int64_t)i * DOT_BLOCKS + lane];
-    const double sr = wave_sum(p.x), si = wave_sum(p.y);
-    if (lane == 0) out[i] = make_double2(sr, si);
+    const double2 r = reduce_partials(partial + (int64_t)i * DOT_BLOCKS, threadIdx.x);
+    if (threadIdx.x == 0) out[i] = r;
 }
 
 // fused: c = reduce(partial); w += sign * V c ; norm_partial[b] = |w_new slice|^2 ; block 0 writes c to c_out
+// (c_out may be host-pinned memory: the Lanczos driver reads alpha_j from it after the stream sync)
 __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__ w, const double2* __restrict__ V,
                                                            int64_t ldv, int nvec,
                                                            const double2* __restrict__ partial,
@@ -84,12 +98,11 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__
     __shared__ double red[DOT_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = wave; i < nvec; i += DOT_THREADS / 64) {
-        const double2 p = partial[(int64_t)i * DOT_BLOCKS + lane];
-        const double sr = wave_sum(p.x), si = wave_sum(p.y);
+        const double2 r = reduce_partials(partial + (int64_t)i * DOT_BLOCKS, lane);
         if (lane == 0) {
-            cs[i][0] = sr;
-            cs[i][1] = si;
-            if (blockIdx.x == 0) c_out[i] = make_double2(sr, si);
+            cs[i][0] = r.x;
+            cs[i][1] = r.y;
+            if (blockIdx.x == 0) c_out[i] = r;
         }
     }
     __syncthreads();
@@ -128,7 +141,10 @@ __global__ __launch_bounds__(DOT_THREADS) void k_scale_by_norm(double2* __restri
     __shared__ double s_inv;
     const int tid = threadIdx.x;
     if (tid < 64) {
-        const double t = wave_sum(norm_partial[tid]);
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < DOT_BLOCKS / 64; ++b) t += norm_partial[tid + 64 * b];
+        t = wave_sum(t);
         if (tid == 0) {
             s_inv = t > 0.0 ? 1.0 / sqrt(t) : 0.0;
             if (blockIdx.x == 0 && nrm2_out) nrm2_out[0] = t;
@@ -231,54 +247,66 @@ extern "C" int htn_scale_inv_sqrt_z(void* dst, const void* src, const void* nrm2
 // ----------------------------------------------------------------------------------------------
 // host side of the Lanczos driver
 // ----------------------------------------------------------------------------------------------
-// lowest eigenpair of the symmetric tridiagonal (alpha, beta) by cyclic Jacobi on the dense k x k
-// matrix (k <= 64: microseconds on the host, unconditionally convergent, no LAPACK dependency)
+// lowest eigenpair of the symmetric tridiagonal (alpha, beta): bisection on the Sturm sequence for the
+// eigenvalue, then inverse iteration with a shift just below it (T - mu I is positive definite, so the
+// LDL^T tridiagonal solve needs no pivoting).  O(k) per step: microseconds for k <= 64.
+static int sturm_count(const std::vector<double>& a, const std::vector<double>& b, double x) {
+    int cnt = 0;
+    double d = 1.0;
+    const int k = (int)a.size();
+    for (int i = 0; i < k; ++i) {
+        const double off = i ? b[i - 1] * b[i - 1] : 0.0;
+        d = (a[i] - x) - (i ? off / d : 0.0);
+        if (d == 0.0) d = 1e-300;
+        if (d < 0.0) ++cnt;
+    }
+    return cnt;        // number of eigenvalues < x
+}
+
 static void tridiag_lowest(const std::vector<double>& alpha, const std::vector<double>& beta, double* eig,
                            std::vector<double>& vec) {
     const int k = (int)alpha.size();
-    std::vector<double> A(k * k, 0.0), Q(k * k, 0.0);
+    double lo = alpha[0], hi = alpha[0];
     for (int i = 0; i < k; ++i) {
-        A[i * k + i] = alpha[i];
-        Q[i * k + i] = 1.0;
-        if (i + 1 < k) A[i * k + i + 1] = A[(i + 1) * k + i] = beta[i];
+        const double r = (i ? fabs(beta[i - 1]) : 0.0) + (i + 1 < k ? fabs(beta[i]) : 0.0);
+        lo = fmin(lo, alpha[i] - r);
+        hi = fmax(hi, alpha[i] + r);
     }
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, diag = 0.0;
-        for (int i = 0; i < k; ++i) {
-            diag += A[i * k + i] * A[i * k + i];
-            for (int j = i + 1; j < k; ++j) off += A[i * k + j] * A[i * k + j];
-        }
-        if (off <= 1e-32 * (diag + off)) break;
-        for (int p = 0; p < k - 1; ++p)
-            for (int q = p + 1; q < k; ++q) {
-                const double apq = A[p * k + q];
-                if (apq == 0.0) continue;
-                const double zeta = (A[q * k + q] - A[p * k + p]) / (2.0 * apq);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int r = 0; r < k; ++r) {
-                    const double arp = A[r * k + p], arq = A[r * k + q];
-                    A[r * k + p] = c * arp - s * arq;
-                    A[r * k + q] = s * arp + c * arq;
-                }
-                for (int r = 0; r < k; ++r) {
-                    const double apr = A[p * k + r], aqr = A[q * k + r];
-                    A[p * k + r] = c * apr - s * aqr;
-                    A[q * k + r] = s * apr + c * aqr;
-                }
-                for (int r = 0; r < k; ++r) {
-                    const double qrp = Q[r * k + p], qrq = Q[r * k + q];
-                    Q[r * k + p] = c * qrp - s * qrq;
-                    Q[r * k + q] = s * qrp + c * qrq;
-                }
-            }
+    const double scale = fmax(fabs(lo), fabs(hi)) + 1e-300;
+    hi = hi + 1e-12 * scale;
+    for (int it = 0; it < 200 && hi - lo > 4e-16 * scale; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (sturm_count(alpha, beta, mid) >= 1) hi = mid;
+        else lo = mid;
     }
-    int best = 0;
-    for (int i = 1; i < k; ++i)
-        if (A[i * k + i] < A[best * k + best]) best = i;
-    *eig = A[best * k + best];
-    vec.resize(k);
-    for (int r = 0; r < k; ++r) vec[r] = Q[r * k + best];
+    const double lam = 0.5 * (lo + hi);
+    *eig = lam;
+    vec.assign(k, 1.0 / sqrt((double)k));
+    if (k == 1) {
+        vec[0] = 1.0;
+        return;
+    }
+    const double mu = lam - 1e-10 * scale;
+    std::vector<double> d(k), l(k), z(k);
+    d[0] = alpha[0] - mu;
+    for (int i = 1; i < k; ++i) {
+        l[i] = beta[i - 1] / d[i - 1];
+        d[i] = (alpha[i] - mu) - l[i] * beta[i - 1];
+        if (d[i] == 0.0) d[i] = 1e-300;
+    }
+    for (int i = 0; i < k; ++i) vec[i] = (i & 1) ? -0.7 : 1.0;   // not orthogonal to the lowest vector in practice
+    for (int iter = 0; iter < 4; ++iter) {
+        z[0] = vec[0];
+        for (int i = 1; i < k; ++i) z[i] = vec[i] - l[i] * z[i - 1];
+        z[k - 1] /= d[k - 1];
+        for (int i = k - 2; i >= 0; --i) z[i] = z[i] / d[i] - l[i + 1] * z[i + 1];
+        double nn = 0.0;
+        for (int i = 0; i < k; ++i) nn += z[i] * z[i];
+        nn = 1.0 / sqrt(nn);
+        for (int i = 0; i < k; ++i) vec[i] = z[i] * nn;
+    }
+    if (vec[0] < 0.0)
+        for (int i = 0; i < k; ++i) vec[i] = -vec[i];
 }
 
 extern "C" int64_t htn_lanczos_scratch_elems(int32_t krylovdim) {
@@ -302,12 +330,21 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
     double* norm_partial = (double*)(ycoef + (kd + 1));
     double* nrm2 = norm_partial + DOT_BLOCKS;
 
-    static thread_local double2* h_c = nullptr;     // pinned staging for the per-iteration D2H
-    if (!h_c) HIP_TRY(hipHostMalloc((void**)&h_c, sizeof(double2) * (2 * 64 + 2 + 64)));
+    // host-pinned, device-mapped: the kernels write alpha / beta^2 straight into host memory (no copy
+    // kernel per iteration); valid on the host after the stream synchronise
+    static thread_local double2* h_c = nullptr;
+    static thread_local double2* d_c = nullptr;
+    if (!h_c) {
+        HIP_TRY(hipHostMalloc((void**)&h_c, sizeof(double2) * (2 * 64 + 2 + 64), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&d_c, h_c, 0));
+    }
     double2* h_c1 = h_c;
     double2* h_c2 = h_c + 64;
     double* h_n = (double*)(h_c + 128);
     double2* h_y = h_c + 130;
+    c1 = d_c;                 // device views of the pinned block
+    c2 = d_c + 64;
+    nrm2 = (double*)(d_c + 128);
 
     auto matvec = [&](double2* x, double2* y) -> int {
         if (zero_y) HIP_TRY(hipMemsetAsync(y, 0, sizeof(double2) * n, st));
@@ -353,9 +390,6 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
                                -1.0, n, norm_partial);
             // v_{j+1} = w / |w| ; also leaves |w|^2 in nrm2
             hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, w, w, norm_partial, n, nrm2);
-            HIP_TRY(hipMemcpyAsync(h_c1 + j, c1 + j, sizeof(double2), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(h_c2 + j, c2 + j, sizeof(double2), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(h_n, nrm2, sizeof(double), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (matvec_ms_host) {
                 float ms = 0.f;

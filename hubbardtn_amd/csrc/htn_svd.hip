@@ -27,7 +27,8 @@ __device__ __forceinline__ double group_sum(double v) {
 
 template <int GS>
 __device__ __forceinline__ double jacobi_pair(double2* ga, double2* gb, double2* __restrict__ va,
-                                              double2* __restrict__ vb, int m, int n, int sub, double tol) {
+                                              double2* __restrict__ vb, int m, int n, int sub, double tol,
+                                              bool accumulate, double zero2) {
     double2 a[JAC_MAXEL], b[JAC_MAXEL];
     double aa = 0.0, bb = 0.0, gr = 0.0, gi = 0.0;
 #pragma unroll
@@ -46,9 +47,12 @@ __device__ __forceinline__ double jacobi_pair(double2* ga, double2* gb, double2*
     bb = group_sum<GS>(bb);
     gr = group_sum<GS>(gr);
     gi = group_sum<GS>(gi);
+    // a column below 1e-15 |G|_F is numerically zero (surplus columns of a wide or rank-deficient block):
+    // its direction is rounding noise and must not keep the sweep loop alive
+    if (aa <= zero2 || bb <= zero2) return 0.0;
     const double g = sqrt(gr * gr + gi * gi);
     const double den = sqrt(aa * bb);
-    if (g == 0.0 || g <= tol * den) return den > 0.0 ? g / den : 0.0;
+    if (g == 0.0 || g <= tol * den) return g / den;
     const double zeta = (bb - aa) / (2.0 * g);
     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
     const double c = 1.0 / sqrt(1.0 + t * t);
@@ -64,18 +68,19 @@ __device__ __forceinline__ double jacobi_pair(double2* ga, double2* gb, double2*
             gb[i] = make_double2(s * a[e].x + c * bt.x, s * a[e].y + c * bt.y);
         }
     }
-    for (int i = sub; i < n; i += GS) {
-        const double2 x = va[i], y = vb[i];
-        const double2 yt = make_double2(pr * y.x - pi * y.y, pr * y.y + pi * y.x);
-        va[i] = make_double2(c * x.x - s * yt.x, c * x.y - s * yt.y);
-        vb[i] = make_double2(s * x.x + c * yt.x, s * x.y + c * yt.y);
-    }
+    if (accumulate)
+        for (int i = sub; i < n; i += GS) {
+            const double2 x = va[i], y = vb[i];
+            const double2 yt = make_double2(pr * y.x - pi * y.y, pr * y.y + pi * y.x);
+            va[i] = make_double2(c * x.x - s * yt.x, c * x.y - s * yt.y);
+            vb[i] = make_double2(s * x.x + c * yt.x, s * x.y + c * yt.y);
+        }
     return g / den;
 }
 
 template <int GS>
 __device__ __forceinline__ int jacobi_sweeps(double2* g, double2* __restrict__ v, int m, int n, int max_sweeps,
-                                             double tol, double* s_ratio, int tid) {
+                                             double tol, double* s_ratio, int tid, bool accumulate, double zero2) {
     const int grp = tid / GS, sub = tid % GS;
     const int ngroups = JAC_THREADS / GS;
     const int np = n + (n & 1);      // padded to even; index np-1 == n is a bye when n is odd
@@ -99,7 +104,7 @@ __device__ __forceinline__ int jacobi_sweeps(double2* g, double2* __restrict__ v
                 if (i < n && j < n) {
                     const int lo = i < j ? i : j, hi = i < j ? j : i;
                     const double rr = jacobi_pair<GS>(g + (int64_t)lo * m, g + (int64_t)hi * m, v + (int64_t)lo * n,
-                                                      v + (int64_t)hi * n, m, n, sub, tol);
+                                                      v + (int64_t)hi * n, m, n, sub, tol, accumulate, zero2);
                     ratio = rr > ratio ? rr : ratio;
                 }
             }
@@ -117,6 +122,124 @@ __device__ __forceinline__ int jacobi_sweeps(double2* g, double2* __restrict__ v
     return done ? sweeps : -sweeps;
 }
 
+// ---- QR with column pivoting (modified Gram-Schmidt, R only) ---------------------------------------
+// Preconditioner of Drmac-Veselic type: G0 P = Q R, then Jacobi runs on X = R^H whose columns are graded
+// by the pivoting, which cuts the sweep count from ~18 to a few on Schmidt-type (graded) spectra.  Q is
+// never needed: G0 = (Q J) Sigma (P W)^H, and P W -- the normalised Jacobi output with its rows permuted
+// back -- is exactly the isometry the caller asked for (it staged G0 = M^H or M accordingly).
+// Columns are not swapped physically: s_col[k] is the physical column of logical position k.
+template <int GS>
+__device__ __forceinline__ void qrcp_mgs(double2* __restrict__ g0, int m0, int n0, int r, double2* X, int ldx,
+                                         int* s_col, double* s_cn2, double* s_piv, int tid) {
+    const int grp = tid / GS, sub = tid % GS, lane = tid & 63, wave = tid >> 6;
+    const int ngroups = JAC_THREADS / GS;
+    for (int idx = tid; idx < ldx * r; idx += JAC_THREADS) X[idx] = make_double2(0.0, 0.0);
+    for (int k = grp; k < n0; k += ngroups) {
+        double c = 0.0;
+        for (int i = sub; i < m0; i += GS) {
+            const double2 x = g0[(int64_t)k * m0 + i];
+            c += x.x * x.x + x.y * x.y;
+        }
+        c = group_sum<GS>(c);
+        if (sub == 0) {
+            s_cn2[k] = c;
+            s_col[k] = k;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double f = 0.0;
+        for (int k = lane; k < n0; k += 64) f += s_cn2[k];
+        f = wave_sum(f);
+        if (lane == 0) s_piv[1] = 1e-30 * f;       // "numerically zero" threshold on squared norms
+    }
+    __syncthreads();
+    const double zero2 = s_piv[1];
+    for (int j = 0; j < r; ++j) {
+        if (wave == 0) {                            // pivot = remaining column of largest norm
+            double best = -1.0;
+            int bi = j;
+            for (int k = j + lane; k < n0; k += 64)
+                if (s_cn2[k] > best) {
+                    best = s_cn2[k];
+                    bi = k;
+                }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (ob > best || (ob == best && oi < bi)) {
+                    best = ob;
+                    bi = oi;
+                }
+            }
+            if (bi != j)                             // the finished part of R moves with its column
+                for (int jj = lane; jj < j; jj += 64) {
+                    const double2 t = X[(int64_t)jj * ldx + j];
+                    X[(int64_t)jj * ldx + j] = X[(int64_t)jj * ldx + bi];
+                    X[(int64_t)jj * ldx + bi] = t;
+                }
+            if (lane == 0) {
+                const int t = s_col[j];
+                s_col[j] = s_col[bi];
+                s_col[bi] = t;
+                s_cn2[bi] = s_cn2[j];
+                s_cn2[j] = best;
+                s_piv[0] = best;
+            }
+        }
+        __syncthreads();
+        if (s_piv[0] <= zero2) break;               // numerically rank deficient: remaining R rows are zero
+        const double2* __restrict__ p = g0 + (int64_t)s_col[j] * m0;
+        for (int k = j + grp; k < n0; k += ngroups) {
+            // every group recomputes |p|^2 itself (bitwise identical everywhere): no normalisation pass
+            double2 pv[JAC_MAXEL], av[JAC_MAXEL];
+            double pp = 0.0, dr = 0.0, di = 0.0;
+            double2* __restrict__ a = g0 + (int64_t)s_col[k] * m0;
+#pragma unroll
+            for (int e = 0; e < JAC_MAXEL; ++e) {
+                const int i = sub + GS * e;
+                if (i < m0) {
+                    pv[e] = p[i];
+                    pp += pv[e].x * pv[e].x + pv[e].y * pv[e].y;
+                    if (k > j) {
+                        av[e] = a[i];
+                        dr += pv[e].x * av[e].x + pv[e].y * av[e].y;      // conj(p) * a
+                        di += pv[e].x * av[e].y - pv[e].y * av[e].x;
+                    }
+                }
+            }
+            pp = group_sum<GS>(pp);
+            const double pn = sqrt(pp);
+            if (k == j) {
+                if (sub == 0) X[(int64_t)j * ldx + j] = make_double2(pn, 0.0);
+                continue;
+            }
+            dr = group_sum<GS>(dr);
+            di = group_sum<GS>(di);
+            const double fr = dr / pp, fi = di / pp;      // (p^H a) / |p|^2
+            double c = 0.0;
+#pragma unroll
+            for (int e = 0; e < JAC_MAXEL; ++e) {
+                const int i = sub + GS * e;
+                if (i < m0) {
+                    const double2 x = make_double2(av[e].x - (fr * pv[e].x - fi * pv[e].y),
+                                                   av[e].y - (fr * pv[e].y + fi * pv[e].x));
+                    a[i] = x;
+                    c += x.x * x.x + x.y * x.y;
+                }
+            }
+            c = group_sum<GS>(c);
+            if (sub == 0) {
+                s_cn2[k] = c;
+                X[(int64_t)j * ldx + k] = make_double2(dr / pn, -di / pn);   // conj(r_jk), r_jk = q^H a
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict__ G, double2* __restrict__ Vj,
                                                             double* __restrict__ S,
                                                             const htn_svd_block* __restrict__ desc,
@@ -124,6 +247,9 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
                                                             int lds_elems) {
     extern __shared__ double2 g_lds[];
     __shared__ double s_ratio;
+    __shared__ double s_piv[2];
+    __shared__ int s_col[64 * JAC_MAXEL];
+    __shared__ double s_cn2[64 * JAC_MAXEL];
     const htn_svd_block D = desc[blockIdx.x];
     const int m = D.m, n = D.n;
     double2* __restrict__ gglob = G + D.g_off;
@@ -131,27 +257,56 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwaves = JAC_THREADS / 64;
     const bool in_lds = (int64_t)m * n <= lds_elems;
-    // V = identity ; stage G into LDS when it fits
-    for (int idx = tid; idx < n * n; idx += JAC_THREADS) {
-        const int i = idx % n, j = idx / n;
-        v[idx] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+    const bool accumulate = (D.flags & HTN_SVD_ACCUMULATE) != 0;
+    const bool qrcp = (D.flags & HTN_SVD_QRCP) != 0;
+    double2* g;
+    if (qrcp) {
+        // G0 (m0 x n0 = D.pad x D.m) at gglob; X = R^H (n0 x r = m x n) in LDS or in the Vj workspace
+        const int m0 = D.pad;
+        g = in_lds ? (double2*)g_lds : v;
+        if (m0 <= 16 * JAC_MAXEL) qrcp_mgs<16>(gglob, m0, m, n, g, m, s_col, s_cn2, s_piv, tid);
+        else if (m0 <= 32 * JAC_MAXEL) qrcp_mgs<32>(gglob, m0, m, n, g, m, s_col, s_cn2, s_piv, tid);
+        else qrcp_mgs<64>(gglob, m0, m, n, g, m, s_col, s_cn2, s_piv, tid);
+    } else {
+        // V = identity ; stage G into LDS when it fits
+        if (accumulate)
+            for (int idx = tid; idx < n * n; idx += JAC_THREADS) {
+                const int i = idx % n, j = idx / n;
+                v[idx] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+            }
+        if (in_lds)
+            for (int idx = tid; idx < m * n; idx += JAC_THREADS) g_lds[idx] = gglob[idx];
+        __syncthreads();
+        g = in_lds ? (double2*)g_lds : gglob;
     }
-    if (in_lds)
-        for (int idx = tid; idx < m * n; idx += JAC_THREADS) g_lds[idx] = gglob[idx];
+    // |G|_F^2 -> threshold for "numerically zero" columns
+    {
+        double f = 0.0;
+        for (int idx = tid; idx < m * n; idx += JAC_THREADS) {
+            const double2 x = g[idx];
+            f += x.x * x.x + x.y * x.y;
+        }
+        f = wave_sum(f);
+        if (tid == 0) s_ratio = 0.0;
+        __syncthreads();
+        if (lane == 0) atomicAdd(&s_ratio, f);
+        __syncthreads();
+    }
+    const double zero2 = 1e-30 * s_ratio;
     __syncthreads();
-    double2* g = in_lds ? (double2*)g_lds : gglob;
     int sw;
-    if (m <= 16 * JAC_MAXEL) sw = jacobi_sweeps<16>(g, v, m, n, max_sweeps, tol, &s_ratio, tid);
-    else if (m <= 32 * JAC_MAXEL) sw = jacobi_sweeps<32>(g, v, m, n, max_sweeps, tol, &s_ratio, tid);
-    else sw = jacobi_sweeps<64>(g, v, m, n, max_sweeps, tol, &s_ratio, tid);
+    if (m <= 16 * JAC_MAXEL) sw = jacobi_sweeps<16>(g, v, m, n, max_sweeps, tol, &s_ratio, tid, accumulate, zero2);
+    else if (m <= 32 * JAC_MAXEL) sw = jacobi_sweeps<32>(g, v, m, n, max_sweeps, tol, &s_ratio, tid, accumulate, zero2);
+    else sw = jacobi_sweeps<64>(g, v, m, n, max_sweeps, tol, &s_ratio, tid, accumulate, zero2);
     __syncthreads();
-    // column norms (+ write back)
+    // column norms (+ write back; the QR path undoes the pivoting: row k of X is row s_col[k] of the result)
     for (int j = wave; j < n; j += nwaves) {
         double s = 0.0;
         for (int i = lane; i < m; i += 64) {
             const double2 x = g[(int64_t)j * m + i];
             s += x.x * x.x + x.y * x.y;
-            if (in_lds) gglob[(int64_t)j * m + i] = x;
+            if (qrcp) gglob[(int64_t)j * m + s_col[i]] = x;
+            else if (in_lds) gglob[(int64_t)j * m + i] = x;
         }
         s = wave_sum(s);
         if (lane == 0) S[D.s_off + j] = sqrt(s);

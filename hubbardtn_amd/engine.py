@@ -200,7 +200,7 @@ class DMRG2:
         t_lan = time.perf_counter() - t0 - t_plan
         x = V[0:n]
         # ---- SVD + truncation ----
-        sp = pl.plan_svd(tl)
+        sp = pl.plan_svd(tl, placement)
         nb = len(sp.mids)
         G = ops.empty_z(max(sp.g_size, 1))
         Vj = ops.empty_z(max(sp.v_size, 1))
@@ -223,20 +223,20 @@ class DMRG2:
         mid = Bond({c: k for c, k in keep.items() if k > 0})
         layA = SiteLayout.build("L", bl, mid)
         layB = SiteLayout.build("R", mid, br)
-        A_g, A_v, B_g, B_v, idx = pl.plan_finalize(tl, sp, order, keep, layA, layB, placement)
-        bufA = ops.zeros_z(max(layA.size, 1))
-        bufB = ops.zeros_z(max(layB.size, 1))
+        offA, offB = 0, layA.size
+        iso_g, cen_g, iso_v, idx, cen_tasks = pl.plan_finalize(tl, sp, order, keep, layA, layB, placement, offA, offB)
+        out = ops.zeros_z(max(layA.size + layB.size, 1))
         idx_d = ops.to_device(idx)
-        gA = 1.0 if placement == "right" else 1.0 / nrm
-        gB = 1.0 / nrm if placement == "right" else 1.0
-        if len(A_g):
-            ops.batched_copy(bufA, G, idx_d, S, ops.to_device(A_g), len(A_g), gA)
-        if len(A_v):
-            ops.batched_copy(bufA, Vj, idx_d, S, ops.to_device(A_v), len(A_v), gA)
-        if len(B_g):
-            ops.batched_copy(bufB, G, idx_d, S, ops.to_device(B_g), len(B_g), gB)
-        if len(B_v):
-            ops.batched_copy(bufB, Vj, idx_d, S, ops.to_device(B_v), len(B_v), gB)
+        if len(iso_g):
+            ops.batched_copy(out, G, idx_d, S, ops.to_device(iso_g), len(iso_g), 1.0)
+        if len(cen_g):
+            ops.batched_copy(out, G, idx_d, S, ops.to_device(cen_g), len(cen_g), 1.0 / nrm)
+        if len(iso_v):
+            ops.batched_copy(out, Vj, idx_d, S, ops.to_device(iso_v), len(iso_v), 1.0)
+        if cen_tasks is not None:
+            cen_tasks.segs["alpha_re"] *= 1.0 / nrm
+            ops.grouped_gemm(self._bufs(x=x, s1=out, y=out), ops.upload_tasks(cen_tasks))
+        bufA, bufB = out[offA:offA + max(layA.size, 1)], out[offB:offB + max(layB.size, 1)]
         self.bonds[i + 1] = mid
         self.site_lay[i], self.site_buf[i] = layA, bufA
         self.site_lay[i + 1], self.site_buf[i + 1] = layB, bufB

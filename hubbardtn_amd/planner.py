@@ -543,6 +543,7 @@ class SvdPlan:
     stage: np.ndarray           # COPY_DT items copying M_c or M_c^H into the Jacobi workspace
     mids: list
     transposed: list            # per block: True if G = M^H
+    accumulate: list            # per block: True if the rotation J is accumulated (mode B)
     g_size: int
     v_size: int
     s_size: int
@@ -550,30 +551,63 @@ class SvdPlan:
     flops: int                  # LAPACK-equivalent flops, SURVEY 8(d)
 
 
-def plan_svd(tl: ThetaLayout):
+def plan_svd(tl: ThetaLayout, placement: str, qrcp: bool = True):
+    """Jacobi staging for all coupled blocks.  Default (qrcp): stage G0 = M^H ('right') or M ('left'); the
+    kernel preconditions it by pivoted QR and runs Jacobi on R^H, returning (isometry x Sigma) directly
+    -- handled downstream exactly like mode A below.  Without qrcp:  The sweep direction decides which isometry is needed
+    (placement 'right': U, 'left': V).  Mode A stages the block so that the normalised Jacobi output
+    IS that isometry (no rotation accumulated; the centre tensor follows from one GEMM with M);
+    mode B (block much wider than tall in that orientation) orthogonalises the short side instead and
+    accumulates the rotation J, which then is the wanted isometry."""
     n = len(tl.mids)
     desc = np.zeros(max(n, 1), dtype=SVD_DT)
     stage = np.zeros(max(n, 1), dtype=COPY_DT)
     go = vo = so = 0
-    transposed = []
+    transposed, accumulate = [], []
     max_m = 0
     flops = 0
     for i, c in enumerate(tl.mids):
         off, rows, cols = tl.mats[c][:3]
-        tr = rows < cols
-        m, nn = (cols, rows) if tr else (rows, cols)
-        desc[i] = (go, vo, so, m, nn)
+        mA, nA = (rows, cols) if placement == "right" else (cols, rows)
+        if qrcp and max(rows, cols) <= 512:
+            m0, n0 = nA, mA                   # G0 is m0 x n0; Jacobi works on R^H: n0 x r
+            r = min(m0, n0)
+            desc[i] = (go, vo, so, n0, r, 2, m0)
+            st = stage[i]
+            st["dst_off"], st["src_off"], st["idx_off"], st["scl_off"] = go, off, -1, -1
+            st["rows"], st["cols"], st["ldd"], st["lds"] = m0, n0, m0, rows
+            st["op"], st["gather_dim"], st["scale_dim"], st["inv_norm"] = (OP_C if placement == "right" else OP_N), 0, -1, 0
+            transposed.append(placement != "right")
+            accumulate.append(False)
+            go += m0 * n0
+            vo += n0 * r
+            so += r
+            max_m = max(max_m, m0, n0)
+            mm, kk = max(rows, cols), min(rows, cols)
+            flops += 4 * (4 * mm * kk * kk + 8 * kk ** 3)
+            continue
+        modeA = (nA <= 1.25 * mA and mA <= 512) or nA > 512
+        if modeA:
+            m, nn, tr, acc = mA, nA, placement != "right", False
+        else:
+            m, nn, tr, acc = nA, mA, placement == "right", True
+        if m > 512:
+            raise NotImplementedError("coupled block taller than 512 rows in both orientations")
+        desc[i] = (go, vo, so, m, nn, 1 if acc else 0, 0)
         st = stage[i]
         st["dst_off"], st["src_off"], st["idx_off"], st["scl_off"] = go, off, -1, -1
         st["rows"], st["cols"], st["ldd"], st["lds"] = m, nn, m, rows
         st["op"], st["gather_dim"], st["scale_dim"], st["inv_norm"] = (OP_C if tr else OP_N), 0, -1, 0
         transposed.append(tr)
+        accumulate.append(acc)
         go += m * nn
-        vo += nn * nn
+        vo += nn * nn if acc else 0
         so += nn
         max_m = max(max_m, m)
-        flops += 4 * (4 * m * nn * nn + 8 * nn ** 3)
-    return SvdPlan(desc[:max(n, 1)], stage[:max(n, 1)], list(tl.mids), transposed, go, vo, so, max_m, flops)
+        mm, kk = max(rows, cols), min(rows, cols)
+        flops += 4 * (4 * mm * kk * kk + 8 * kk ** 3)
+    return SvdPlan(desc[:max(n, 1)], stage[:max(n, 1)], list(tl.mids), transposed, accumulate, go, vo, so, max_m,
+                   flops)
 
 
 def truncate(svals: dict, chi_full=None, cutoff=0.0, weighting="sqrtdim", rel_floor=1e-14):
@@ -607,50 +641,61 @@ def truncate(svals: dict, chi_full=None, cutoff=0.0, weighting="sqrtdim", rel_fl
 
 
 def plan_finalize(tl: ThetaLayout, sp: SvdPlan, order: dict, keep: dict, layA: SiteLayout, layB: SiteLayout,
-                  placement: str):
-    """copy items writing the truncated A (left layout, BUF dst A) and B (right layout, dst B).
-    order[c] = permutation sorting the Jacobi column norms descending; keep[c] = kept count.
-    Returns (itemsA_from_G, itemsA_from_V, itemsB_from_G, itemsB_from_V, idx array)."""
+                  placement: str, offA: int, offB: int):
+    """Writes the truncated A (left layout) and B (right layout) into ONE output buffer (A at offA, B at
+    offB).  order[c] = permutation sorting the Jacobi column norms descending; keep[c] = kept count.
+    Returns (iso_g, cen_g, iso_v copy-item arrays, idx array, centre Tasks | None):
+      iso_g : isometry columns taken from G' and divided by sigma           (global scale 1)
+      cen_g : centre tensor taken from G' (mode B; sigma cancels)           (global scale 1/nrm)
+      iso_v : isometry taken from the accumulated rotation J (mode B)       (global scale 1)
+      centre Tasks: mode-A centres, U^H M or M V, as grouped-GEMM segments with alpha = 1 (scaled by the
+      caller through alpha_scale) -- buffers: BUF_X = theta, BUF_S1 = BUF_Y = the output buffer."""
     idx = []
-    A_g, A_v, B_g, B_v = [], [], [], []
+    iso_g, cen_g, iso_v = [], [], []
+    cen = TaskList()
+    right = placement == "right"
     for i, c in enumerate(sp.mids):
         k = keep.get(c, 0)
         if k == 0:
             continue
         off, rows, cols = tl.mats[c][:3]
-        g_off, v_off, s_off, m, nn = (int(x) for x in sp.desc[i])
+        g_off, v_off, s_off, m, nn = (int(sp.desc[i][f]) for f in ("g_off", "v_off", "s_off", "m", "n"))
         ioff = len(idx)
         idx.extend(int(p) for p in order[c][:k])
-        oA = layA.mats[c][0]
-        oB = layB.mats[c][0]
-        tr = sp.transposed[i]
+        oA = offA + layA.mats[c][0]
+        oB = offB + layB.mats[c][0]
+        tr, acc = sp.transposed[i], sp.accumulate[i]
         itA = np.zeros((), dtype=COPY_DT)
         itB = np.zeros((), dtype=COPY_DT)
-        # A (rows x k), ld rows.  U = G'[:,p]/sigma (not transposed) or J[:,p] (transposed)
+        # A (rows x k, ld rows): gather columns ; B (k x cols, ld k): conjugate-transposed gather of columns
         itA["dst_off"], itA["rows"], itA["cols"], itA["ldd"] = oA, rows, k, rows
-        itA["idx_off"], itA["gather_dim"], itA["op"] = ioff, 1, OP_N
-        itA["scl_off"] = s_off
-        if not tr:
-            itA["src_off"], itA["lds"] = g_off, m
-            itA["scale_dim"], itA["inv_norm"] = (1, 1) if placement == "right" else (-1, 0)
-            A_g.append(itA)
-        else:
-            itA["src_off"], itA["lds"] = v_off, nn
-            itA["scale_dim"], itA["inv_norm"] = (-1, 0) if placement == "right" else (1, 0)
-            A_v.append(itA)
-        # B (k x cols), ld k.  V^H = conj(J[:,p])^T (not transposed) or conj(G'[:,p])^T/sigma (transposed)
+        itA["idx_off"], itA["gather_dim"], itA["op"], itA["scl_off"] = ioff, 1, OP_N, s_off
         itB["dst_off"], itB["rows"], itB["cols"], itB["ldd"] = oB, k, cols, k
-        itB["idx_off"], itB["gather_dim"], itB["op"] = ioff, 0, OP_C
-        itB["scl_off"] = s_off
-        if not tr:
-            itB["src_off"], itB["lds"] = v_off, nn
-            itB["scale_dim"], itB["inv_norm"] = (0, 0) if placement == "right" else (-1, 0)
-            B_v.append(itB)
-        else:
-            itB["src_off"], itB["lds"] = g_off, m
-            itB["scale_dim"], itB["inv_norm"] = (-1, 0) if placement == "right" else (0, 1)
-            B_g.append(itB)
+        itB["idx_off"], itB["gather_dim"], itB["op"], itB["scl_off"] = ioff, 0, OP_C, s_off
+        if right and not acc:            # mode A: G = M, G' = U Sigma
+            itA["src_off"], itA["lds"], itA["scale_dim"], itA["inv_norm"] = g_off, m, 1, 1
+            iso_g.append(itA)
+            key = ("cen", c)
+            cen.block(key, BUF_Y, oB, k, cols, k)
+            cen.gemm(key, BUF_S1, oA, rows, OP_C, BUF_X, off, rows, OP_N, rows, 1.0)        # U^H M
+        elif right and acc:              # mode B: G = M^H, G' = V Sigma, J = U
+            itA["src_off"], itA["lds"], itA["scale_dim"], itA["inv_norm"] = v_off, nn, -1, 0
+            iso_v.append(itA)
+            itB["src_off"], itB["lds"], itB["scale_dim"], itB["inv_norm"] = g_off, m, -1, 0
+            cen_g.append(itB)            # S V^H = conj(G')^T
+        elif (not right) and not acc:    # mode A: G = M^H, G' = V Sigma
+            itB["src_off"], itB["lds"], itB["scale_dim"], itB["inv_norm"] = g_off, m, 0, 1
+            iso_g.append(itB)
+            key = ("cen", c)
+            cen.block(key, BUF_Y, oA, rows, k, rows)
+            cen.gemm(key, BUF_X, off, rows, OP_N, BUF_S1, oB, k, OP_C, cols, 1.0)           # M V
+        else:                            # mode B: G = M, G' = U Sigma, J = V
+            itB["src_off"], itB["lds"], itB["scale_dim"], itB["inv_norm"] = v_off, nn, -1, 0
+            iso_v.append(itB)
+            itA["src_off"], itA["lds"], itA["scale_dim"], itA["inv_norm"] = g_off, m, -1, 0
+            cen_g.append(itA)            # U S = G'
 
     def arr(lst):
         return np.array(lst, dtype=COPY_DT) if lst else np.zeros(0, dtype=COPY_DT)
-    return arr(A_g), arr(A_v), arr(B_g), arr(B_v), np.array(idx if idx else [0], dtype=np.int32)
+    cen_tasks = cen.finalize() if cen.blocks else None
+    return arr(iso_g), arr(cen_g), arr(iso_v), np.array(idx if idx else [0], dtype=np.int32), cen_tasks

@@ -122,16 +122,22 @@ int htn_lanczos_z(const htn_gemm_launch* stages_host, int32_t n_stages, int32_t 
 /* Batched one-sided Jacobi SVD of the coupled-sector blocks of a two-site tensor.
  * Stands in for: TensorKit tsvd!(t; alg=SVD()) -> LAPACK zgesvd per block (SURVEY.md 8a a9,
  * scheme chosen at src/HubbardFunctions.jl:1010 and :1363-1365).
- * For block i the m_i x n_i (m_i >= n_i, column-major, ld = m_i) matrix at G + g_off[i] is
- * overwritten by G*J (mutually orthogonal columns), the n_i x n_i rotation J is written at
- * Vj + v_off[i] (ld = n_i), and the UNSORTED column norms at S + s_off[i].
- * The caller transposes blocks with rows < cols beforehand (htn_svd_finalize undoes it).
+ * For block i the m_i x n_i (column-major, ld = m_i) matrix at G + g_off[i] is overwritten by G*J
+ * (mutually orthogonal columns = sigma_j u_j, UNSORTED; surplus columns of a wide block converge to 0),
+ * the column norms go to S + s_off[i] and, if flags & HTN_SVD_ACCUMULATE, the n_i x n_i rotation J to
+ * Vj + v_off[i] (ld = n_i).  The caller stages M or M^H (htn_batched_copy_z) so that the isometry the
+ * sweep direction needs is the normalised G*J itself; the other factor is then a plain GEMM with M.
  * desc: device array of htn_svd_block; max_m_host = max_i m_i (<= 512 in this version).
  * info_dev[i] receives the sweep count (<0: not converged). */
+#define HTN_SVD_ACCUMULATE 1      /* flags: also accumulate the rotation J (else Vj is not touched) */
+#define HTN_SVD_QRCP 2            /* flags: the block at g_off is G0 (pad x m, ld = pad); pivoted-QR precondition it,
+                                     run Jacobi on R^H (m x n, n = min(pad, m)) and write the m x n result
+                                     (rows un-pivoted, ld = m) back to g_off; the v_off region (>= m*n) is scratch */
 typedef struct {
     int64_t g_off, v_off, s_off;
     int32_t m, n;
-} htn_svd_block;        /* 32 bytes */
+    int32_t flags, pad;
+} htn_svd_block;        /* 40 bytes */
 int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc, int32_t n_blocks,
                      int32_t max_m_host, int32_t max_sweeps, double tol, int32_t* info_dev, void* stream);
 

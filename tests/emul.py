@@ -137,15 +137,33 @@ class NumpyOps:
         for b in range(nblocks):
             d = desc[b]
             m, n = int(d["m"]), int(d["n"])
+            if int(d["flags"]) & abi.SVD_QRCP:
+                # G0 (m0 x m) -> right singular vectors x Sigma (m x n), unsorted, arbitrary phases
+                m0 = int(d["pad"])
+                g0 = G[int(d["g_off"]):int(d["g_off"]) + m0 * m].reshape(m, m0).T
+                U, s, Vh = np.linalg.svd(g0, full_matrices=False)
+                perm = self.rng.permutation(n)
+                ph = np.exp(2j * np.pi * self.rng.random(n))
+                out = (Vh.conj().T[:, :n] * s[:n])[:, perm] * ph
+                G[int(d["g_off"]):int(d["g_off"]) + m * n] = out.T.reshape(-1)
+                S[int(d["s_off"]):int(d["s_off"]) + n] = s[:n][perm]
+                info[b] = 1
+                continue
             g = G[int(d["g_off"]):int(d["g_off"]) + m * n].reshape(n, m).T
-            U, s, Vh = np.linalg.svd(g, full_matrices=False)
+            U, s, Vh = np.linalg.svd(g, full_matrices=True)
+            r = min(m, n)
+            sfull = np.zeros(n)
+            sfull[:r] = s
+            gp = np.zeros((m, n), dtype=np.complex128)
+            gp[:, :r] = U[:, :r] * s
             perm = self.rng.permutation(n)             # Jacobi leaves the columns unsorted
             ph = np.exp(2j * np.pi * self.rng.random(n))  # and with arbitrary phases
-            gp = (U * s)[:, perm] * ph
+            gp = gp[:, perm] * ph
             J = Vh.conj().T[:, perm] * ph
             G[int(d["g_off"]):int(d["g_off"]) + m * n] = gp.T.reshape(-1)
-            Vj[int(d["v_off"]):int(d["v_off"]) + n * n] = J.T.reshape(-1)
-            S[int(d["s_off"]):int(d["s_off"]) + n] = s[perm]
+            if int(d["flags"]) & abi.SVD_ACCUMULATE:
+                Vj[int(d["v_off"]):int(d["v_off"]) + n * n] = J.T.reshape(-1)
+            S[int(d["s_off"]):int(d["s_off"]) + n] = sfull[perm]
             info[b] = 1
 
     def batched_copy(self, dst, src, idx, scl, items, nitems, gscale):

@@ -98,43 +98,98 @@ def test_krylov_vector_algebra(hip_ops):
     assert abs(np.linalg.norm(hip_ops.to_host(dw)) - 1.0) < 1e-13
 
 
-@pytest.mark.parametrize("shapes", [[(1, 1), (2, 1), (5, 5), (17, 9), (64, 64), (70, 33)], [(130, 130), (200, 90), (3, 2)]])
-def test_jacobi_svd_matches_lapack(hip_ops, shapes):
+@pytest.mark.parametrize("shapes,acc", [([(1, 1), (2, 1), (5, 5), (17, 9), (64, 64), (70, 33)], True),
+                                        ([(130, 130), (200, 90), (3, 2)], True),
+                                        ([(60, 60), (40, 52), (140, 150), (3, 7)], False)])
+def test_jacobi_svd_matches_lapack(hip_ops, shapes, acc):
+    """G' = G J has orthogonal columns whose norms are the singular values; wide blocks (m < n) end with
+    n - m zero columns; J is only written when HTN_SVD_ACCUMULATE is set"""
     rng = np.random.default_rng(4)
     desc = np.zeros(len(shapes), dtype=abi.SVD_DT)
     go = vo = so = 0
     mats = []
     for i, (m, n) in enumerate(shapes):
-        desc[i] = (go, vo, so, m, n)
+        desc[i] = (go, vo, so, m, n, abi.SVD_ACCUMULATE if acc else 0, 0)
+        r = min(m, n)
         # graded spectrum like a Schmidt spectrum: singular values over 12 decades
-        U, _ = np.linalg.qr(_rand_z(rng, m * n).reshape(m, n))
-        W, _ = np.linalg.qr(_rand_z(rng, n * n).reshape(n, n))
-        s = 10.0 ** (-12 * np.arange(n) / max(n - 1, 1))
+        U, _ = np.linalg.qr(_rand_z(rng, m * r).reshape(m, r))
+        W, _ = np.linalg.qr(_rand_z(rng, n * r).reshape(n, r))
+        s = 10.0 ** (-12 * np.arange(r) / max(r - 1, 1))
         mats.append((U * s) @ W.conj().T)
         go, vo, so = go + m * n, vo + n * n, so + n
     G = np.concatenate([M.T.reshape(-1) for M in mats])
     dG = hip_ops.to_device(G)
-    dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
+    sentinel = 7.0 + 3.0j
+    dV = hip_ops.to_device(np.full(vo, sentinel))
+    dS, info = hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
     hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), max(m for m, _ in shapes), 40, 1e-14, info)
     Gp, J, S, inf = hip_ops.to_host(dG), hip_ops.to_host(dV), hip_ops.to_host(dS), hip_ops.to_host(info)
     assert inf.min() >= 0, inf          # negative = not converged; 0 = nothing to do (n < 2)
+    if not acc:
+        assert np.all(J == sentinel)
     for i, (m, n) in enumerate(shapes):
         d = desc[i]
         gp = Gp[d["g_off"]:d["g_off"] + m * n].reshape(n, m).T
-        j = J[d["v_off"]:d["v_off"] + n * n].reshape(n, n).T
         s = S[d["s_off"]:d["s_off"] + n]
-        ref = np.linalg.svd(mats[i], compute_uv=False)
+        ref = np.zeros(n)
+        ref[:min(m, n)] = np.linalg.svd(mats[i], compute_uv=False)
         got = np.sort(s)[::-1]
         # LAPACK (the reference's zgesvd) is accurate to eps * sigma_max ABSOLUTE only, so the relative
         # 1e-8 bar of north_star is checkable against it down to sigma ~ 1e-6 sigma_max
         assert np.abs(got - ref).max() <= 1e-13 * ref[0]
         big = ref > 1e-6 * ref[0]
         assert np.abs(got[big] / ref[big] - 1).max() < 1e-8
-        assert np.abs(j.conj().T @ j - np.eye(n)).max() < 1e-13          # J unitary
-        assert np.abs(mats[i] @ j - gp).max() < 1e-13                     # G' = M J
         gram = gp.conj().T @ gp
-        off = gram - np.diag(np.diag(gram))
-        assert np.abs(off).max() <= 1e-13 * ref[0] ** 2 + 1e-13 * np.sqrt(np.outer(np.diag(gram).real, np.diag(gram).real)).max()
+        dg = np.sqrt(np.abs(np.diag(gram)))
+        live = dg > 1e-14 * ref[0]        # columns below 1e-15 |G|_F are treated as zero by the kernel
+        off = np.abs(gram - np.diag(np.diag(gram)))[np.ix_(live, live)]
+        assert (off <= 1e-13 * np.outer(dg[live], dg[live])).all()      # live columns mutually orthogonal
+        assert live.sum() >= (ref > 1e-13 * ref[0]).sum()
+        if acc:
+            j = J[d["v_off"]:d["v_off"] + n * n].reshape(n, n).T
+            assert np.abs(j.conj().T @ j - np.eye(n)).max() < 1e-13          # J unitary
+            assert np.abs(mats[i] @ j - gp).max() < 1e-13                     # G' = M J
+
+
+@pytest.mark.parametrize("shapes", [[(1, 1), (2, 3), (40, 40), (33, 57), (57, 33)], [(107, 107), (150, 93), (93, 150)]])
+def test_jacobi_svd_qr_preconditioned(hip_ops, shapes):
+    """HTN_SVD_QRCP: G0 (m0 x n0) -> (right singular vectors of G0) x Sigma, n0 x min(m0, n0), rows in the
+    ORIGINAL column order of G0; few sweeps on graded spectra"""
+    rng = np.random.default_rng(8)
+    desc = np.zeros(len(shapes), dtype=abi.SVD_DT)
+    go = vo = so = 0
+    mats = []
+    for i, (m0, n0) in enumerate(shapes):
+        r = min(m0, n0)
+        desc[i] = (go, vo, so, n0, r, abi.SVD_QRCP, m0)
+        U, _ = np.linalg.qr(_rand_z(rng, m0 * r).reshape(m0, r))
+        W, _ = np.linalg.qr(_rand_z(rng, n0 * r).reshape(n0, r))
+        s = 10.0 ** (-12 * np.arange(r) / max(r - 1, 1))
+        mats.append((U * s) @ W.conj().T)
+        go, vo, so = go + m0 * n0, vo + n0 * r, so + r
+    dG = hip_ops.to_device(np.concatenate([M.T.reshape(-1) for M in mats]))
+    dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
+    hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), max(max(s_) for s_ in shapes), 40, 1e-14, info)
+    Gp, S, inf = hip_ops.to_host(dG), hip_ops.to_host(dS), hip_ops.to_host(info)
+    assert inf.min() >= 0, inf
+    assert inf.max() <= 10, inf                   # preconditioning keeps the sweep count small
+    for i, (m0, n0) in enumerate(shapes):
+        d = desc[i]
+        r = min(m0, n0)
+        out = Gp[d["g_off"]:d["g_off"] + n0 * r].reshape(r, n0).T        # n0 x r, ld n0
+        s = S[d["s_off"]:d["s_off"] + r]
+        ref = np.linalg.svd(mats[i], compute_uv=False)
+        order = np.argsort(-s)
+        assert np.abs(s[order] - ref).max() <= 1e-13 * ref[0]
+        big = ref > 1e-6 * ref[0]
+        assert np.abs(s[order][big] / ref[big] - 1).max() < 1e-8
+        live = s > 1e-13 * ref[0]
+        Viso = out[:, live] / s[live]
+        assert np.abs(Viso.conj().T @ Viso - np.eye(live.sum())).max() < 1e-12       # orthonormal columns
+        # they are right singular vectors of G0:  |G0 v| = sigma and G0^H G0 v = sigma^2 v
+        assert np.abs(np.linalg.norm(mats[i] @ Viso, axis=0) - s[live]).max() <= 1e-12 * ref[0]
+        resid = mats[i].conj().T @ (mats[i] @ Viso) - Viso * s[live] ** 2
+        assert np.abs(resid).max() <= 1e-12 * ref[0] ** 2
 
 
 def test_batched_copy_matches_numpy(hip_ops):
