@@ -27,8 +27,43 @@ static inline int htn_fail_msg(const char* what) {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// ---- cross-lane sums -------------------------------------------------------------------------------
+// Within a row of 16 lanes the butterfly runs on DPP (pure VALU, no LDS crossbar round trip):
+// quad_perm xor-1, quad_perm xor-2, row_half_mirror, row_mirror.  Across rows ds_bpermute (__shfl_xor).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double row_sum16(double v) {      // all-reduce inside each aligned 16-lane row
+    v += dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);    // row_half_mirror
+    v += dpp_f64<0x140>(v);    // row_mirror
     return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {       // all-reduce over the 64 lanes
+    v = row_sum16(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// ---- fast reciprocal / reciprocal square root: hardware seed + 2 Newton steps (full f64 accuracy for
+// normal-range arguments; the precise library versions expand to 20-40 instructions each) ------------
+__device__ __forceinline__ double fast_rcp(double a) {
+    double x = __builtin_amdgcn_rcp(a);
+    x = fma(fma(-a, x, 1.0), x, x);
+    x = fma(fma(-a, x, 1.0), x, x);
+    return x;
+}
+__device__ __forceinline__ double fast_rsq(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    const double h = 0.5 * a;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
 }

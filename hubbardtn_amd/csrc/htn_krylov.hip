@@ -14,8 +14,8 @@
 
 #include "htn_common.h"
 
-#define DOT_BLOCKS 128        // partial sums per vector (2 per lane of the reducing wave)
-#define DOT_THREADS 256
+#define DOT_BLOCKS 256        // partial sums per vector = slices of the vector (4 per lane of the reducing wave)
+#define DOT_THREADS 256       // threads of the axpy / scale kernels
 #define DOT_CHUNK 32          // vectors handled per pass over the slice of w (krylovdim + 1 <= 31 by default)
 
 // sum of the DOT_BLOCKS partials of one vector by one wave, fixed order
@@ -30,13 +30,13 @@ __device__ __forceinline__ double2 reduce_partials(const double2* __restrict__ p
     return make_double2(wave_sum(sr), wave_sum(si));
 }
 
-// partial[i * DOT_BLOCKS + b] = sum over slice b of conj(V_i) * w.  One pass over the slice for up to 32
-// vectors: every thread issues all its loads back to back (latency, not bandwidth, bounds this kernel).
-__global__ __launch_bounds__(DOT_THREADS) void k_dots_partial(const double2* __restrict__ V, int64_t ldv,
-                                                              int nvec, const double2* __restrict__ w,
-                                                              int64_t n, double2* __restrict__ partial) {
-    __shared__ double red[DOT_THREADS / 64][DOT_CHUNK][2];
-    const int tid = threadIdx.x;
+// partial[i * DOT_BLOCKS + b] = sum over slice b of conj(V_i) * w.  ONE WAVE per slice: every lane issues
+// all its loads back to back (latency, not bandwidth, bounds this kernel at |theta| ~ 10^5) and the only
+// reduction is the in-wave butterfly -- no LDS stage, no barrier.
+__global__ __launch_bounds__(64) void k_dots_partial(const double2* __restrict__ V, int64_t ldv, int nvec,
+                                                     const double2* __restrict__ w, int64_t n,
+                                                     double2* __restrict__ partial) {
+    const int lane = threadIdx.x;
     const int64_t per = (n + DOT_BLOCKS - 1) / DOT_BLOCKS;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(DOT_THREADS) void k_dots_partial(const double2* __r
         double sr[DOT_CHUNK], si[DOT_CHUNK];
 #pragma unroll
         for (int c = 0; c < DOT_CHUNK; ++c) sr[c] = si[c] = 0.0;
-        for (int64_t j = lo + tid; j < hi; j += DOT_THREADS) {
+        for (int64_t j = lo + lane; j < hi; j += 64) {
             const double2 b = w[j];
 #pragma unroll
             for (int c = 0; c < DOT_CHUNK; ++c) {
@@ -60,23 +60,9 @@ __global__ __launch_bounds__(DOT_THREADS) void k_dots_partial(const double2* __r
             if (i0 + c < nvec) {
                 const double r = wave_sum(sr[c]);
                 const double m = wave_sum(si[c]);
-                if ((tid & 63) == 0) {
-                    red[tid >> 6][c][0] = r;
-                    red[tid >> 6][c][1] = m;
-                }
+                if (lane == 0) partial[(int64_t)(i0 + c) * DOT_BLOCKS + blockIdx.x] = make_double2(r, m);
             }
         }
-        __syncthreads();
-        if (tid < DOT_CHUNK && i0 + tid < nvec) {
-            double tr = 0.0, ti = 0.0;
-#pragma unroll
-            for (int q = 0; q < DOT_THREADS / 64; ++q) {
-                tr += red[q][tid][0];
-                ti += red[q][tid][1];
-            }
-            partial[(int64_t)(i0 + tid) * DOT_BLOCKS + blockIdx.x] = make_double2(tr, ti);
-        }
-        __syncthreads();
     }
 }
 
@@ -219,7 +205,7 @@ extern "C" int htn_dots_z(const void* V, int64_t ldv, int32_t nvec, const void* 
                           void* scratch, void* stream) {
     if (nvec <= 0) return 0;
     if (nvec > 64) return fail_msg("htn_dots_z: nvec > 64");
-    hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(64), 0, (hipStream_t)stream,
                        (const double2*)V, ldv, nvec, (const double2*)w, n, (double2*)scratch);
     hipLaunchKernelGGL(k_dots_reduce, dim3(nvec), dim3(64), 0, (hipStream_t)stream, (const double2*)scratch,
                        nvec, (double2*)out);
@@ -382,10 +368,10 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
             if (matvec_ms_host) HIP_TRY(hipEventRecord(ev1, st));
             ++nmv;
             // two passes of classical Gram-Schmidt against ALL Krylov vectors (full reorthogonalisation)
-            hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, j + 1, w, n, partial);
+            hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(64), 0, st, V, n, j + 1, w, n, partial);
             hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial, c1,
                                -1.0, n, norm_partial);
-            hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, j + 1, w, n, partial);
+            hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(64), 0, st, V, n, j + 1, w, n, partial);
             hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial, c2,
                                -1.0, n, norm_partial);
             // v_{j+1} = w / |w| ; also leaves |w|^2 in nrm2

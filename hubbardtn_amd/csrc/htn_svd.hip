@@ -19,9 +19,10 @@
 #define JAC_MAXEL 8           // column elements per lane kept in registers: m <= GS * JAC_MAXEL
 
 template <int GS>
-__device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int off = GS / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+__device__ __forceinline__ double group_sum(double v) {      // all-reduce inside aligned groups of GS lanes
+    v = row_sum16(v);
+    if (GS >= 32) v += __shfl_xor(v, 16, 64);
+    if (GS >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
@@ -50,15 +51,22 @@ __device__ __forceinline__ double jacobi_pair(double2* ga, double2* gb, double2*
     // a column below 1e-15 |G|_F is numerically zero (surplus columns of a wide or rank-deficient block):
     // its direction is rounding noise and must not keep the sweep loop alive
     if (aa <= zero2 || bb <= zero2) return 0.0;
-    const double g = sqrt(gr * gr + gi * gi);
-    const double den = sqrt(aa * bb);
-    if (g == 0.0 || g <= tol * den) return g / den;
-    const double zeta = (bb - aa) / (2.0 * g);
-    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-    const double c = 1.0 / sqrt(1.0 + t * t);
+    const double g2 = gr * gr + gi * gi;
+    const double ab = aa * bb;
+    const double ratio2 = g2 * fast_rcp(ab);          // (|a.b| / (|a||b|))^2
+    if (g2 == 0.0 || g2 <= tol * tol * ab) return ratio2;
+    // rotation diagonalising [[aa, gamma], [conj gamma, bb]]:  t = sign(h) 2g / (|h| + sqrt(h^2 + 4 g^2)), h = bb - aa
+    const double ig = fast_rsq(g2);
+    const double g = g2 * ig;
+    const double h = bb - aa;
+    const double w2 = fma(h, h, 4.0 * g2);
+    const double w = w2 * fast_rsq(w2);
+    double t = 2.0 * g * fast_rcp(fabs(h) + w);
+    t = h >= 0.0 ? t : -t;
+    const double c = fast_rsq(fma(t, t, 1.0));
     const double s = c * t;
     // b~ = exp(-i phi) b with exp(i phi) = gamma / |gamma|;  a' = c a - s b~ ; b' = s a + c b~
-    const double pr = gr / g, pi = -gi / g;   // exp(-i phi)
+    const double pr = gr * ig, pi = -gi * ig;   // exp(-i phi)
 #pragma unroll
     for (int e = 0; e < JAC_MAXEL; ++e) {
         const int i = sub + GS * e;
@@ -75,7 +83,7 @@ __device__ __forceinline__ double jacobi_pair(double2* ga, double2* gb, double2*
             va[i] = make_double2(c * x.x - s * yt.x, c * x.y - s * yt.y);
             vb[i] = make_double2(s * x.x + c * yt.x, s * x.y + c * yt.y);
         }
-    return g / den;
+    return ratio2;
 }
 
 template <int GS>
@@ -113,10 +121,10 @@ __device__ __forceinline__ int jacobi_sweeps(double2* g, double2* __restrict__ v
         // workgroup max of the non-negative ratio: doubles order like their bit patterns
         if (sub == 0 && ratio > 0.0) atomicMax((unsigned long long*)s_ratio, (unsigned long long)__double_as_longlong(ratio));
         __syncthreads();
-        const double mx = *s_ratio;
+        const double mx = *s_ratio;  // max over the sweep of the SQUARED cosine between column pairs
         ++sweeps;
-        done = last || mx <= tol;
-        last = mx < 1e-8;            // quadratic convergence: the next sweep is the final one
+        done = last || mx <= tol * tol;
+        last = mx < 1e-16;           // quadratic convergence: the next sweep is the final one
         __syncthreads();
     }
     return done ? sweeps : -sweeps;

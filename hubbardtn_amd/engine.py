@@ -67,6 +67,8 @@ class DMRG2:
         self.shard = shard
         self.profile = False
         self.bonds = [Bond(b) for b in bonds]
+        self._plan_cache = {}
+        self.cache_hits = self.cache_misses = 0
         self.site_lay = [None] * self.L
         self.site_buf = [None] * self.L
         for i in range(self.L):
@@ -84,11 +86,33 @@ class DMRG2:
         self.energy = None
         self.stats = []
         self.spectra = {}
-        self._plan_cache = {}
+
+    # ---- plan cache --------------------------------------------------------------------------------
+    # Task lists depend only on the sector tables of the bonds involved (and the MPO site), not on the
+    # tensor data, and in converged sweeps the same tables recur bond after bond, sweep after sweep.
+    # Like TensorKit's global fusion-tree-transformer caches, compiled plans (already uploaded) are
+    # memoised by those tables.
+    def _cached(self, key, builder):
+        hit = self._plan_cache.get(key)
+        if hit is None:
+            if len(self._plan_cache) > 20000:
+                self._plan_cache.clear()
+            hit = builder()
+            self._plan_cache[key] = hit
+            self.cache_misses += 1
+        else:
+            self.cache_hits += 1
+        return hit
+
+    def _site_layout(self, kind, bl, br):
+        return self._cached(("slay", kind, bl.key(), br.key()), lambda: SiteLayout.build(kind, bl, br))
+
+    def _theta_layout(self, bl, br):
+        return self._cached(("tl", bl.key(), br.key()), lambda: ThetaLayout.build(bl, br))
 
     # ---- host <-> device site tensors -----------------------------------------------------------
     def _upload_site(self, i, blocks, kind):
-        lay = SiteLayout.build(kind, self.bonds[i], self.bonds[i + 1])
+        lay = self._site_layout(kind, self.bonds[i], self.bonds[i + 1])
         flat = np.zeros(max(lay.size, 1), dtype=np.complex128)
         for key, (off, m, n, ld) in lay.blocks.items():
             blk = blocks.get(key)
@@ -128,46 +152,59 @@ class DMRG2:
         ops = self.ops
         lay = self.site_lay[i]
         assert lay.kind == "L"
-        Lnew = EnvLayout.build("L", self.bonds[i + 1], self.mpo[i].right)
-        t1, t2, zsize = pl.plan_left_env(self.Llay[i], lay, self.mpo[i], Lnew)
+
+        def build():
+            Lnew = EnvLayout.build("L", self.bonds[i + 1], self.mpo[i].right)
+            t1, t2, zsize = pl.plan_left_env(self.Llay[i], lay, self.mpo[i], Lnew)
+            return Lnew, ops.upload_tasks(t1), ops.upload_tasks(t2), zsize, t1.flops + t2.flops
+        Lnew, d1, d2, zsize, flops = self._cached(("lenv", i, self.bonds[i].key(), self.bonds[i + 1].key()), build)
         z = ops.empty_z(max(zsize, 1))
         out = ops.empty_z(max(Lnew.size, 1))
-        ops.grouped_gemm(self._bufs(l=self.Lbuf[i], s1=self.site_buf[i], z=z), ops.upload_tasks(t1))
-        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], z=z, y=out), ops.upload_tasks(t2))
+        ops.grouped_gemm(self._bufs(l=self.Lbuf[i], s1=self.site_buf[i], z=z), d1)
+        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], z=z, y=out), d2)
         self.Llay[i + 1], self.Lbuf[i + 1] = Lnew, out
-        return t1.flops + t2.flops
+        return flops
 
     def _right_env(self, i):
         """GR on bond i from GR on bond i+1 and the right-layout tensor of site i"""
         ops = self.ops
         lay = self.site_lay[i]
         assert lay.kind == "R"
-        Rnew = EnvLayout.build("R", self.bonds[i], self.mpo[i].left)
-        t1, t2, zsize = pl.plan_right_env(self.Rlay[i + 1], lay, self.mpo[i], Rnew)
+
+        def build():
+            Rnew = EnvLayout.build("R", self.bonds[i], self.mpo[i].left)
+            t1, t2, zsize = pl.plan_right_env(self.Rlay[i + 1], lay, self.mpo[i], Rnew)
+            return Rnew, ops.upload_tasks(t1), ops.upload_tasks(t2), zsize, t1.flops + t2.flops
+        Rnew, d1, d2, zsize, flops = self._cached(("renv", i, self.bonds[i].key(), self.bonds[i + 1].key()), build)
         z = ops.empty_z(max(zsize, 1))
         out = ops.empty_z(max(Rnew.size, 1))
-        ops.grouped_gemm(self._bufs(r=self.Rbuf[i + 1], s1=self.site_buf[i], z=z), ops.upload_tasks(t1))
-        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], z=z, y=out), ops.upload_tasks(t2))
+        ops.grouped_gemm(self._bufs(r=self.Rbuf[i + 1], s1=self.site_buf[i], z=z), d1)
+        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], z=z, y=out), d2)
         self.Rlay[i], self.Rbuf[i] = Rnew, out
-        return t1.flops + t2.flops
+        return flops
 
     # ---- effective Hamiltonian --------------------------------------------------------------------
     def _make_apply(self, i, tl):
         """stage list of the H_eff apply on bond (i, i+1): [(buffer table, device task list), ...]"""
         ops = self.ops
-        tz, ty, zsize, nterms = pl.plan_apply(tl, self.Llay[i], self.Rlay[i + 2], self.mpo[i], self.mpo[i + 1])
-        flops = ty.flops + (tz.flops if tz is not None else 0)
-        ntiles = ty.ntiles + (tz.ntiles if tz else 0)
-        nsegs = ty.nsegs + (tz.nsegs if tz else 0)
-        if self.shard is not None:
-            rank, world, _ = self.shard
-            ty = _shard_tasks(ty, rank, world)
+
+        def build():
+            tz, ty, zsize, nterms = pl.plan_apply(tl, self.Llay[i], self.Rlay[i + 2], self.mpo[i], self.mpo[i + 1])
+            flops = ty.flops + (tz.flops if tz is not None else 0)
+            ntiles = ty.ntiles + (tz.ntiles if tz else 0)
+            nsegs = ty.nsegs + (tz.nsegs if tz else 0)
+            if self.shard is not None:
+                rank, world, _ = self.shard
+                ty = _shard_tasks(ty, rank, world)
+            return (ops.upload_tasks(tz) if tz is not None else None, ops.upload_tasks(ty), zsize, flops, ntiles, nsegs)
+        dz, dy, zsize, flops, ntiles, nsegs = self._cached(
+            ("apply", i, self.bonds[i].key(), self.bonds[i + 2].key()), build)
         z = ops.empty_z(max(zsize, 1))
         Lb, Rb = self.Lbuf[i], self.Rbuf[i + 2]
         stages = []
-        if tz is not None:
-            stages.append((self._bufs(l=Lb, z=z), ops.upload_tasks(tz)))
-        stages.append((self._bufs(l=Lb, r=Rb, z=z), ops.upload_tasks(ty)))
+        if dz is not None:
+            stages.append((self._bufs(l=Lb, z=z), dz))
+        stages.append((self._bufs(l=Lb, r=Rb, z=z), dy))
         nbytes = 16 * (2 * tl.size + self.Llay[i].size + self.Rlay[i + 2].size)
         return stages, flops, nbytes, ntiles, nsegs
 
@@ -178,7 +215,7 @@ class DMRG2:
         t0 = time.perf_counter()
         ops = self.ops
         bl, br = self.bonds[i], self.bonds[i + 2]
-        tl = ThetaLayout.build(bl, br)
+        tl = self._theta_layout(bl, br)
         n = tl.size
         kd = self.krylovdim
         lay1, lay2 = self.site_lay[i], self.site_lay[i + 1]
@@ -186,8 +223,9 @@ class DMRG2:
         assert mode in ("RR", "LL", "LR"), mode
         V = ops.empty_z((kd + 2) * n)
         # theta -> V[0] (the Lanczos driver normalises it)
-        tth = pl.plan_theta(mode, lay1, lay2, tl)
-        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], s2=self.site_buf[i + 1], y=V[0:n]), ops.upload_tasks(tth))
+        dth = self._cached(("theta", mode, bl.key(), self.bonds[i + 1].key(), br.key()),
+                           lambda: ops.upload_tasks(pl.plan_theta(mode, lay1, lay2, tl)))
+        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], s2=self.site_buf[i + 1], y=V[0:n]), dth)
         stages, aflops, abytes, ntiles, nsegs = self._make_apply(i, tl)
         if self.profile:
             ops.sync()
@@ -200,14 +238,16 @@ class DMRG2:
         t_lan = time.perf_counter() - t0 - t_plan
         x = V[0:n]
         # ---- SVD + truncation ----
-        sp = pl.plan_svd(tl, placement)
+        sp, d_stage, d_desc = self._cached(("svd", placement, bl.key(), br.key()),
+                                           lambda: (lambda p_: (p_, ops.to_device(p_.stage), ops.to_device(p_.desc)))(
+                                               pl.plan_svd(tl, placement)))
         nb = len(sp.mids)
         G = ops.empty_z(max(sp.g_size, 1))
         Vj = ops.empty_z(max(sp.v_size, 1))
         S = ops.empty_f64(max(sp.s_size, 1))
         info = ops.empty_i32(max(nb, 1))
-        ops.batched_copy(G, x, None, None, ops.to_device(sp.stage), nb, 1.0)
-        ops.jacobi_svd(G, Vj, S, ops.to_device(sp.desc), nb, sp.max_m, self.jacobi_max_sweeps, self.jacobi_tol, info)
+        ops.batched_copy(G, x, None, None, d_stage, nb, 1.0)
+        ops.jacobi_svd(G, Vj, S, d_desc, nb, sp.max_m, self.jacobi_max_sweeps, self.jacobi_tol, info)
         s_host = ops.to_host(S)
         info_h = ops.to_host(info)
         if nb and int(info_h[:nb].min()) < 0:
@@ -221,8 +261,8 @@ class DMRG2:
             svals[c] = s[p]
         keep, tw, nrm = pl.truncate(svals, self.chi_full, self.cutoff, self.weighting)
         mid = Bond({c: k for c, k in keep.items() if k > 0})
-        layA = SiteLayout.build("L", bl, mid)
-        layB = SiteLayout.build("R", mid, br)
+        layA = self._site_layout("L", bl, mid)
+        layB = self._site_layout("R", mid, br)
         offA, offB = 0, layA.size
         iso_g, cen_g, iso_v, idx, cen_tasks = pl.plan_finalize(tl, sp, order, keep, layA, layB, placement, offA, offB)
         out = ops.zeros_z(max(layA.size + layB.size, 1))

@@ -77,6 +77,7 @@ class Bond:
         items = sorted((k, int(v)) for k, v in dims.items() if v > 0)
         self.secs = [k for k, _ in items]
         self.dims = {k: v for k, v in items}
+        self._key = tuple(items)
 
     def __contains__(self, sec):
         return sec in self.dims
@@ -91,7 +92,7 @@ class Bond:
         return isinstance(other, Bond) and self.dims == other.dims
 
     def key(self):
-        return tuple(sorted(self.dims.items()))
+        return self._key
 
     @property
     def dim_full(self):

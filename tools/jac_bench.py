@@ -1,0 +1,49 @@
+"""micro-benchmark of k_jacobi_svd on single graded blocks: time vs size / path"""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import torch
+from hubbardtn_amd import abi
+from hubbardtn_amd.device import HipOps
+
+ops = HipOps(0)
+rng = np.random.default_rng(0)
+
+
+def rz(n):
+    return rng.standard_normal(n) + 1j * rng.standard_normal(n)
+
+
+def run(m0, n0, flags, reps=5):
+    r = min(m0, n0)
+    U, _ = np.linalg.qr(rz(m0 * r).reshape(m0, r))
+    W, _ = np.linalg.qr(rz(n0 * r).reshape(n0, r))
+    s = 10.0 ** (-12 * np.arange(r) / max(r - 1, 1))
+    M = (U * s) @ W.conj().T
+    desc = np.zeros(1, dtype=abi.SVD_DT)
+    if flags & abi.SVD_QRCP:
+        desc[0] = (0, 0, 0, n0, r, flags, m0)
+    else:
+        desc[0] = (0, 0, 0, m0, n0, flags, 0)
+    d_desc = ops.to_device(desc)
+    src = ops.to_device(M.T.reshape(-1).copy())
+    G = ops.empty_z(m0 * n0)
+    V = ops.zeros_z(max(n0 * n0, m0 * n0))
+    S = ops.empty_f64(max(m0, n0))
+    info = ops.empty_i32(1)
+    ts = []
+    for _ in range(reps):
+        G.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.jacobi_svd(G, V, S, d_desc, 1, max(m0, n0), 40, 1e-14, info)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return min(ts), int(info.cpu()[0])
+
+
+for (m0, n0) in [(32, 32), (64, 64), (93, 93), (96, 96), (107, 107), (128, 128), (160, 160), (202, 202)]:
+    a = run(m0, n0, abi.SVD_QRCP)
+    b = run(m0, n0, 0)
+    print(f"{m0}x{n0}: qrcp {a[0]:.3f} ms ({a[1]} sweeps)   plain {b[0]:.3f} ms ({b[1]} sweeps)", flush=True)
