@@ -1,0 +1,172 @@
+"""CPU suite for the host logic: model builder, planner task lists and the sweep driver, executed on the
+numpy interpreter of the C-ABI primitives (tests/emul.py) and compared with the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from emul import NumpyOps
+from hubbardtn_amd import api, engine, models, mps, planner as pl
+from oracle import dmrg_su2, ed, mpo as ompo
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_r01.json")))
+
+
+def _as_dict(mpo):
+    return [{"left": W.left, "right": W.right, "entries": W.entries} for W in mpo]
+
+
+def test_ob_sim_constructors_follow_reference():
+    """two positional forms distinguished by a J vector (src/HubbardFunctions.jl:87-92)"""
+    a = models.OB_Sim([1.0, 0.1], [8.0], 0.0, 1, 1, 2.5, 20, spin=False)
+    assert (a.P, a.Q, a.svalue, a.bond_dim, a.period, a.J) == (1, 1, 2.5, 20, 0, [0.0])
+    b = models.OB_Sim([1.0], [4.0], 0.5, [0.0], 1, 2, 3.0)
+    assert (b.mu, b.P, b.Q, b.svalue, b.bond_dim) == (0.5, 1, 2, 3.0, 50)
+    c = models.OB_Sim([1.0], [4.0])
+    assert (c.mu, c.P, c.Q, c.svalue, c.bond_dim) == (0.0, 1, 1, 2.0, 50)
+
+
+@pytest.mark.parametrize("t,u,mu,L", [([1.0], [4.0], 0.0, 4), ([1.0, 0.1], [8.0, 0.5, 0.25], 0.3, 5)])
+def test_one_band_mpo_equals_dense_hamiltonian(t, u, mu, L):
+    H = models.hamiltonian(models.OB_Sim(t, u, mu), L)
+    assert np.abs(ompo.mpo_to_dense(_as_dict(H)) - ed.dense_hamiltonian(L, t, u, mu)).max() < 1e-13
+
+
+def test_multi_band_mpo_equals_dense_hamiltonian():
+    """2 bands snaked onto a chain (InfiniteStrip order, src:491): on-site + inter-cell hopping and
+    direct terms (src:498, 515, 561, 664), diagonal of t as chemical potential (src:861-864)"""
+    t = np.array([[0.3, 1.1, -0.2, 0.0], [1.1, -0.1, 0.7, -0.3]])
+    u = np.array([[5.0, 2.0, 0.4, 0.0], [2.0, 6.0, 0.6, 0.1]])
+    sim = models.MB_Sim(t, u, np.zeros((2, 4)))
+    cells, B = 2, 2
+    n = cells * B
+    M = ompo.mpo_to_dense(_as_dict(models.hamiltonian(sim, cells)))
+    # dense Jordan-Wigner construction
+    from oracle import su2
+    lm = su2.local_matrices()
+
+    def site_op(mats):
+        out = np.eye(1)
+        for s in range(n):
+            out = np.kron(out, mats.get(s, lm["id"]))
+        return out
+
+    def c_op(i, spin):
+        mats = {s: lm["F"] for s in range(i)}
+        mats[i] = lm["a_up"] if spin == 0 else lm["a_dn"]
+        return site_op(mats)
+    c = {(i, s): c_op(i, s) for i in range(n) for s in (0, 1)}
+    nn = {i: site_op({i: lm["n"]}) for i in range(n)}
+    site = lambda b, cell: b + cell * B
+    H = np.zeros((4 ** n, 4 ** n))
+    for cell in range(cells):
+        for b in range(B):
+            i = site(b, cell)
+            H += u[b, b] * site_op({i: lm["docc"]}) - t[b, b] * nn[i]
+        for bi in range(B):
+            for bf in range(B):
+                if bi != bf:
+                    for s in (0, 1):
+                        H += -t[bi, bf] * c[(site(bf, cell), s)].T @ c[(site(bi, cell), s)]      # src:498
+        H += 0.5 * (u[0, 1] + u[1, 0]) * nn[site(0, cell)] @ nn[site(1, cell)]                    # src:548-561
+    for cell in range(cells - 1):
+        for bi in range(B):
+            for bf in range(B):
+                i, j = site(bi, cell), site(bf, cell + 1)
+                for s in (0, 1):
+                    h = c[(j, s)].T @ c[(i, s)]
+                    H += -t[bi, B + bf] * (h + h.T)                                               # src:515
+                H += u[bi, B + bf] * nn[i] @ nn[j]                                                # src:664
+    assert np.abs(M - H).max() < 1e-12
+    assert np.abs(M - M.T).max() < 1e-13
+
+
+@pytest.mark.parametrize("name", ["L8_U4_chi64", "L12_t2_chi48"])
+def test_sweep_driver_on_emulator_matches_golden(name):
+    """planner + engine host logic (layouts, 9j coefficients, task lists, truncation, SVD staging) vs the
+    oracle's golden energies / spectra"""
+    rec = GOLD["oracle_runs"][name]
+    L = rec["L"]
+    bonds, tens = mps.random_mps(L, (L, 0), rec["cap"], rec["seed"])
+    eng = engine.DMRG2(NumpyOps(), models.hamiltonian(models.OB_Sim(rec["t"], rec["u"]), L), bonds, tens,
+                       chi_full=rec["chi"])
+    for k in range(rec["sweeps"]):
+        E = eng.sweep()
+        assert abs(E - rec["energies"][k]) <= 1e-9 * abs(E)
+    for b, s in rec["spectra_last_sweep"].items():
+        for c, v in s.items():
+            key = tuple(int(x) for x in c.split(","))
+            assert np.abs(eng.spectra[int(b)][key] - np.asarray(v)).max() < 1e-9
+    assert eng.bond_dims() == rec["bond_dims"]
+    assert eng.cache_hits > 0
+
+
+def test_apply_plan_is_hermitian_and_matches_oracle_terms():
+    """one bond: y = H_eff x from the planner's task list equals the oracle's term-by-term apply"""
+    L, t, u = 8, [1.0], [4.0, 0.5]       # (level order of oracle and product MPOs coincides for range-1 terms)
+    bonds, tens = mps.random_mps(L, (L, 0), 5, 3)
+    ops = NumpyOps()
+    eng = engine.DMRG2(ops, models.hamiltonian(models.OB_Sim(t, u), L), bonds, tens, chi_full=40)
+    for i in range(3):
+        eng.update_bond(i, +1, "right")
+    i = 3
+    tl = pl.ThetaLayout.build(eng.bonds[i], eng.bonds[i + 2])
+    stages, flops, nbytes, ntiles, nsegs = eng._make_apply(i, tl)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(tl.size) + 1j * rng.standard_normal(tl.size)
+    z = rng.standard_normal(tl.size) + 1j * rng.standard_normal(tl.size)
+
+    def apply(v):
+        y = np.zeros(tl.size, dtype=np.complex128)
+        for bufs, tasks in stages:
+            b = list(bufs)
+            b[pl.BUF_X], b[pl.BUF_Y] = v, y
+            ops.grouped_gemm(b, tasks)
+        return y
+    Hx, Hz = apply(x), apply(z)
+    assert abs(np.vdot(z, Hx) - np.vdot(Hz, x)) < 1e-10 * abs(np.vdot(z, Hx))      # Hermitian in the plain metric
+    # oracle on the same environments
+    Lenv = eng.download_env("L", i)
+    Renv = {(bra, w, ket): m.T.copy() for (ket, w, bra), m in eng.download_env("R", i + 2).items()}
+    W = ompo.hubbard_mpo(L, t, u)
+    for a, b in zip(W, eng.mpo):
+        assert a["left"] == b.left and a["right"] == b.right        # identical level order
+    theta = {}
+    for key, (off, m, n, ld) in tl.blocks.items():
+        idx = off + np.arange(m)[:, None] + ld * np.arange(n)[None, :]
+        theta[key] = x[idx]
+    blocks = sorted(theta)
+    terms = dmrg_su2.build_apply_terms(blocks, Lenv, Renv, W[i], W[i + 1])
+    y = dmrg_su2.apply_heff(theta, terms, Lenv, Renv)
+    for key, (off, m, n, ld) in tl.blocks.items():
+        idx = off + np.arange(m)[:, None] + ld * np.arange(n)[None, :]
+        assert np.abs(Hx[idx] - y[key]).max() < 1e-11
+    assert flops > 0 and nbytes > 0
+
+
+def test_planner_truncate_matches_oracle_rule():
+    rng = np.random.default_rng(1)
+    sv = {(10, j): np.sort(rng.random(6))[::-1] for j in (0, 2, 4)}
+    sv[(9, 1)] = np.sort(rng.random(5))[::-1]
+    for chi in (5, 17, 40, None):
+        k1, w1, n1 = pl.truncate(sv, chi)
+        k2, w2 = dmrg_su2.truncate_spectrum(sv, chi)
+        assert k1 == k2 and abs(w1 - w2) < 1e-14
+    k1, _, _ = pl.truncate(sv, None, cutoff=0.3)
+    k2, _ = dmrg_su2.truncate_spectrum(sv, None, cutoff=0.3)
+    assert k1 == k2
+
+
+def test_api_surface_keeps_reference_names():
+    for name in ("OB_Sim", "MB_Sim", "produce_groundstate", "compute_groundstate", "find_groundstate",
+                 "initialize_mps", "hamiltonian", "dim_state", "expectation_value", "truncdim", "truncbelow", "DMRG2"):
+        assert hasattr(api, name)
+    sim = api.OB_Sim([1.0], [4.0], 0.0, 1, 1, 2.0, 6)
+    H = api.hamiltonian(sim, L=6)
+    psi = api.initialize_mps(H, sim.P, sim.bond_dim, ops=NumpyOps())      # emulator injected: CPU test
+    psi, envs, delta = api.find_groundstate(psi, H, api.DMRG2(trscheme=api.truncdim(64), tol=1e-9, maxiter=6))
+    E = float(np.sum(api.expectation_value(psi, H)))
+    ref, _ = ed.SectorED(6, 3, 3, [1.0], [4.0]).ground_state()
+    assert abs(E - ref) < 1e-8 and delta < 1e-9
+    assert api.dim_state(psi)[2] == 64 or api.dim_state(psi)[2] <= 64
