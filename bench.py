@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bonds", type=int, default=1)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="exercise the sharded-apply code path (zero_y + all-reduce hook) even at world size 1")
     return ap.parse_args()
 
 
@@ -94,8 +96,11 @@ def main():
             print(msg, file=sys.stderr, flush=True)
 
     shard = None
-    if world > 1:
+    if world > 1 or args.force_shard:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -132,17 +137,17 @@ def main():
     # ---- timed region ----
     eng.stats.clear()
     ops.event_log = []
-    if world > 1:
+    if shard is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         E = eng.sweep()
     torch.cuda.synchronize()
-    if world > 1:
+    if shard is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if shard is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -200,7 +205,7 @@ def main():
     out["total_runtime_s"] = time.perf_counter() - t_start
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if shard is not None:
         dist.destroy_process_group()
 
 
