@@ -187,6 +187,15 @@ def main():
                      "traffic": None, "launches": k_n, "avg_launch_us": (k_ms * 1e3 / k_n) if k_n else None,
                      "flop_per_launch": (k_fl / world / k_n) if k_n else None},
     }
+    # HBM traffic per launch comes from offline rocprofv3 PMC passes (counters cannot be read live); see
+    # profiles/pmc_traffic.json for how it was collected and corrected
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"L{L}_chi{args.chi}")
+        if pmc and world == 1:
+            out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+            out["roofline"]["algorithmic_bytes_per_launch"] = sum(s.n_matvec * s.apply_bytes for s in stats) / max(tot_mv, 1)
+    except Exception:
+        pass
     log(json.dumps(out))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
