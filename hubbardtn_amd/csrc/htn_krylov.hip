@@ -32,7 +32,9 @@ __device__ __forceinline__ double2 reduce_partials(const double2* __restrict__ p
 
 // partial[i * DOT_BLOCKS + b] = sum over slice b of conj(V_i) * w.  ONE WAVE per slice: every lane issues
 // all its loads back to back (latency, not bandwidth, bounds this kernel at |theta| ~ 10^5) and the only
-// reduction is the in-wave butterfly -- no LDS stage, no barrier.
+// reduction is the in-wave butterfly -- no LDS stage, no barrier.  CH = vectors per pass (compile time, so the
+// loads are unconditional and can all be in flight; indices past nvec are clamped and their sums discarded).
+template <int CH>
 __global__ __launch_bounds__(64) void k_dots_partial(const double2* __restrict__ V, int64_t ldv, int nvec,
                                                      const double2* __restrict__ w, int64_t n,
                                                      double2* __restrict__ partial) {
@@ -40,30 +42,39 @@ __global__ __launch_bounds__(64) void k_dots_partial(const double2* __restrict__
     const int64_t per = (n + DOT_BLOCKS - 1) / DOT_BLOCKS;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
-    for (int i0 = 0; i0 < nvec; i0 += DOT_CHUNK) {
-        double sr[DOT_CHUNK], si[DOT_CHUNK];
+    for (int i0 = 0; i0 < nvec; i0 += CH) {
+        double sr[CH], si[CH];
 #pragma unroll
-        for (int c = 0; c < DOT_CHUNK; ++c) sr[c] = si[c] = 0.0;
+        for (int c = 0; c < CH; ++c) sr[c] = si[c] = 0.0;
         for (int64_t j = lo + lane; j < hi; j += 64) {
             const double2 b = w[j];
+            double2 a[CH];
 #pragma unroll
-            for (int c = 0; c < DOT_CHUNK; ++c) {
-                if (i0 + c < nvec) {
-                    const double2 a = V[(int64_t)(i0 + c) * ldv + j];
-                    sr[c] += a.x * b.x + a.y * b.y;
-                    si[c] += a.x * b.y - a.y * b.x;
-                }
+            for (int c = 0; c < CH; ++c) {
+                const int i = i0 + c < nvec ? i0 + c : nvec - 1;
+                a[c] = V[(int64_t)i * ldv + j];
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                sr[c] += a[c].x * b.x + a[c].y * b.y;
+                si[c] += a[c].x * b.y - a[c].y * b.x;
             }
         }
 #pragma unroll
-        for (int c = 0; c < DOT_CHUNK; ++c) {
-            if (i0 + c < nvec) {
-                const double r = wave_sum(sr[c]);
-                const double m = wave_sum(si[c]);
-                if (lane == 0) partial[(int64_t)(i0 + c) * DOT_BLOCKS + blockIdx.x] = make_double2(r, m);
-            }
+        for (int c = 0; c < CH; ++c) {
+            const double r = wave_sum(sr[c]);
+            const double m = wave_sum(si[c]);
+            if (lane == 0 && i0 + c < nvec) partial[(int64_t)(i0 + c) * DOT_BLOCKS + blockIdx.x] = make_double2(r, m);
         }
     }
+}
+
+static void launch_dots_partial(const double2* V, int64_t ldv, int nvec, const double2* w, int64_t n, double2* partial,
+                                hipStream_t st) {
+    if (nvec <= 4) hipLaunchKernelGGL(k_dots_partial<4>, dim3(DOT_BLOCKS), dim3(64), 0, st, V, ldv, nvec, w, n, partial);
+    else if (nvec <= 8) hipLaunchKernelGGL(k_dots_partial<8>, dim3(DOT_BLOCKS), dim3(64), 0, st, V, ldv, nvec, w, n, partial);
+    else if (nvec <= 16) hipLaunchKernelGGL(k_dots_partial<16>, dim3(DOT_BLOCKS), dim3(64), 0, st, V, ldv, nvec, w, n, partial);
+    else hipLaunchKernelGGL(k_dots_partial<32>, dim3(DOT_BLOCKS), dim3(64), 0, st, V, ldv, nvec, w, n, partial);
 }
 
 // one wave per vector: out[i] = sum_b partial[i][b]
@@ -73,13 +84,13 @@ __global__ void k_dots_reduce(const double2* __restrict__ partial, int nvec, dou
     if (threadIdx.x == 0) out[i] = r;
 }
 
-// fused: c = reduce(partial); w += sign * V c ; norm_partial[b] = |w_new slice|^2 ; block 0 writes c to c_out
-// (c_out may be host-pinned memory: the Lanczos driver reads alpha_j from it after the stream sync)
+// fused: c = reduce(partial); w += sign * V c ; norm_partial[b] = |w_new slice|^2 ; block 0 writes c[c_index]
+// to *c_out (host-pinned memory: the Lanczos driver reads <v_j, w> from a slot private to its step)
 __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__ w, const double2* __restrict__ V,
                                                            int64_t ldv, int nvec,
                                                            const double2* __restrict__ partial,
-                                                           double2* __restrict__ c_out, double sign, int64_t n,
-                                                           double* __restrict__ norm_partial) {
+                                                           double2* __restrict__ c_out, int c_index, double sign,
+                                                           int64_t n, double* __restrict__ norm_partial) {
     __shared__ double cs[64][2];
     __shared__ double red[DOT_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,9 +99,10 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__
         if (lane == 0) {
             cs[i][0] = r.x;
             cs[i][1] = r.y;
-            if (blockIdx.x == 0) c_out[i] = r;
+            if (blockIdx.x == 0 && i == c_index) *c_out = r;
         }
     }
+    if (tid >= nvec && tid < 64) cs[tid][0] = cs[tid][1] = 0.0;      // padding coefficients for the unrolled loop
     __syncthreads();
     const int64_t per = (n + DOT_BLOCKS - 1) / DOT_BLOCKS;
     const int64_t lo = (int64_t)blockIdx.x * per;
@@ -98,10 +110,18 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__
     double nn = 0.0;
     for (int64_t j = lo + tid; j < hi; j += DOT_THREADS) {
         double sr = 0.0, si = 0.0;
-        for (int i = 0; i < nvec; ++i) {
-            const double2 v = V[(int64_t)i * ldv + j];
-            sr += cs[i][0] * v.x - cs[i][1] * v.y;
-            si += cs[i][0] * v.y + cs[i][1] * v.x;
+        for (int i0 = 0; i0 < nvec; i0 += 8) {           // 8 independent loads in flight per step
+            double2 v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int i = i0 + c < nvec ? i0 + c : nvec - 1;
+                v[c] = V[(int64_t)i * ldv + j];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                sr += cs[i0 + c][0] * v[c].x - cs[i0 + c][1] * v[c].y;
+                si += cs[i0 + c][0] * v[c].y + cs[i0 + c][1] * v[c].x;
+            }
         }
         double2 x = w[j];
         x.x += sign * sr;
@@ -205,8 +225,7 @@ extern "C" int htn_dots_z(const void* V, int64_t ldv, int32_t nvec, const void* 
                           void* scratch, void* stream) {
     if (nvec <= 0) return 0;
     if (nvec > 64) return fail_msg("htn_dots_z: nvec > 64");
-    hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(64), 0, (hipStream_t)stream,
-                       (const double2*)V, ldv, nvec, (const double2*)w, n, (double2*)scratch);
+    launch_dots_partial((const double2*)V, ldv, nvec, (const double2*)w, n, (double2*)scratch, (hipStream_t)stream);
     hipLaunchKernelGGL(k_dots_reduce, dim3(nvec), dim3(64), 0, (hipStream_t)stream, (const double2*)scratch,
                        nvec, (double2*)out);
     HIP_TRY(hipGetLastError());
@@ -317,18 +336,24 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
     double* nrm2 = norm_partial + DOT_BLOCKS;
 
     // host-pinned, device-mapped: the kernels write alpha / beta^2 straight into host memory (no copy
-    // kernel per iteration); valid on the host after the stream synchronise
+    // kernel per iteration); valid on the host once the iteration's event has completed
     static thread_local double2* h_c = nullptr;
     static thread_local double2* d_c = nullptr;
+    static thread_local hipEvent_t ev_done[64], ev_mv0[64], ev_mv1[64];
     if (!h_c) {
-        HIP_TRY(hipHostMalloc((void**)&h_c, sizeof(double2) * (2 * 64 + 2 + 64), hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc((void**)&h_c, sizeof(double2) * (4 * 64), hipHostMallocMapped));
         HIP_TRY(hipHostGetDevicePointer((void**)&d_c, h_c, 0));
+        for (int i = 0; i < 64; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreate(&ev_mv0[i]));
+            HIP_TRY(hipEventCreate(&ev_mv1[i]));
+        }
     }
-    double2* h_c1 = h_c;
-    double2* h_c2 = h_c + 64;
-    double* h_n = (double*)(h_c + 128);
-    double2* h_y = h_c + 130;
-    c1 = d_c;                 // device views of the pinned block
+    double2* h_c1 = h_c;                    // [64] <v_j, w> of the first Gram-Schmidt pass
+    double2* h_c2 = h_c + 64;               // [64] second pass
+    double* h_n = (double*)(h_c + 128);     // [64] |w|^2 after orthogonalisation, one slot per iteration
+    double2* h_y = h_c + 192;               // Ritz coefficients staging
+    c1 = d_c;                               // device views of the pinned block
     c2 = d_c + 64;
     nrm2 = (double*)(d_c + 128);
 
@@ -344,52 +369,59 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         if (exchange) exchange(y, n, user);
         return 0;
     };
+    // one Lanczos step, fully enqueued: w = H v_j; two Gram-Schmidt passes against V[0..j]; v_{j+1} = w/|w|
+    auto enqueue_step = [&](int j) -> int {
+        double2* vj = V + (int64_t)j * n;
+        double2* w = V + (int64_t)(j + 1) * n;
+        if (matvec_ms_host) HIP_TRY(hipEventRecord(ev_mv0[j], st));
+        if (matvec(vj, w)) return 1;
+        if (matvec_ms_host) HIP_TRY(hipEventRecord(ev_mv1[j], st));
+        launch_dots_partial(V, n, j + 1, w, n, partial, st);
+        hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial, c1 + j, j,
+                           -1.0, n, norm_partial);
+        launch_dots_partial(V, n, j + 1, w, n, partial, st);
+        hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial, c2 + j, j,
+                           -1.0, n, norm_partial);
+        hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, w, w, norm_partial, n, nrm2 + j);
+        HIP_TRY(hipEventRecord(ev_done[j], st));
+        return 0;
+    };
 
     // normalise the start vector
     hipLaunchKernelGGL(k_norm_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, norm_partial);
     hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, V, V, norm_partial, n,
                        (double*)nullptr);
-    static thread_local hipEvent_t ev0 = nullptr, ev1 = nullptr;   // optional matvec timing (bench roofline)
-    if (matvec_ms_host && !ev0) {
-        HIP_TRY(hipEventCreate(&ev0));
-        HIP_TRY(hipEventCreate(&ev1));
-    }
     double mv_ms = 0.0;
     int nmv = 0;
     double theta = 0.0, res = 0.0, beta = 0.0;
     std::vector<double> y;
     for (int restart = 0; restart <= max_restart; ++restart) {
         std::vector<double> alphas, betas;
+        // Software pipeline of depth 1: step j+1 is enqueued BEFORE the host waits for step j's scalars, so the
+        // GPU never idles during the host's convergence test.  If step j converges, step j+1 was speculative:
+        // it only wrote Krylov row j+2 and scalar slots j+1, which nothing reads afterwards.
+        if (enqueue_step(0)) return 1;
+        ++nmv;
         for (int j = 0; j < kd; ++j) {
-            double2* vj = V + (int64_t)j * n;
-            double2* w = V + (int64_t)(j + 1) * n;
-            if (matvec_ms_host) HIP_TRY(hipEventRecord(ev0, st));
-            if (matvec(vj, w)) return 1;
-            if (matvec_ms_host) HIP_TRY(hipEventRecord(ev1, st));
-            ++nmv;
-            // two passes of classical Gram-Schmidt against ALL Krylov vectors (full reorthogonalisation)
-            hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(64), 0, st, V, n, j + 1, w, n, partial);
-            hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial, c1,
-                               -1.0, n, norm_partial);
-            hipLaunchKernelGGL(k_dots_partial, dim3(DOT_BLOCKS), dim3(64), 0, st, V, n, j + 1, w, n, partial);
-            hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial, c2,
-                               -1.0, n, norm_partial);
-            // v_{j+1} = w / |w| ; also leaves |w|^2 in nrm2
-            hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, w, w, norm_partial, n, nrm2);
-            HIP_TRY(hipStreamSynchronize(st));
+            if (j + 1 < kd) {
+                if (enqueue_step(j + 1)) return 1;
+                ++nmv;
+            }
+            HIP_TRY(hipEventSynchronize(ev_done[j]));
             if (matvec_ms_host) {
                 float ms = 0.f;
-                HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+                HIP_TRY(hipEventElapsedTime(&ms, ev_mv0[j], ev_mv1[j]));
                 mv_ms += ms;
             }
             const double alpha = h_c1[j].x + h_c2[j].x;
-            beta = sqrt(h_n[0] > 0.0 ? h_n[0] : 0.0);
+            beta = sqrt(h_n[j] > 0.0 ? h_n[j] : 0.0);
             alphas.push_back(alpha);
             tridiag_lowest(alphas, betas, &theta, y);
             res = fabs(beta * y.back());
             if (res < tol || beta < 1e-14 || j == kd - 1) break;
             betas.push_back(beta);
         }
+        HIP_TRY(hipStreamSynchronize(st));       // drain the speculative step before rows are reused
         // x = sum_i y_i V_i  -> scratch row kd+1, normalised into row 0
         const int k = (int)y.size();
         for (int i = 0; i < k; ++i) h_y[i] = make_double2(y[i], 0.0);
