@@ -130,6 +130,141 @@ __device__ __forceinline__ int jacobi_sweeps(double2* g, double2* __restrict__ v
     return done ? sweeps : -sweeps;
 }
 
+// column storage split between LDS (first nl columns) and global memory (the rest): blocks slightly larger
+// than the LDS window keep most of their columns at LDS latency.  Generic (flat) pointers.
+struct SplitCols {
+    double2* lds;
+    double2* glob;
+    int nl, mp;
+    __device__ __forceinline__ double2* col(int j) const {
+        return j < nl ? lds + (int64_t)j * mp : glob + (int64_t)(j - nl) * mp;
+    }
+};
+
+// ---- padded fast path (QR-preconditioned blocks) -----------------------------------------------------
+// Columns are stored with leading dimension GS * E (zero padded), so every lane owns exactly E elements
+// of each column: no per-element predication, all loads issued back to back, and the LDS / global address
+// space is known at compile time (ds_* / global_* instead of flat_*).
+template <int GS, int E, typename P>
+__device__ __forceinline__ double jacobi_pair_pad(P ga, P gb, int sub, double tol2, double zero2) {
+    double2 a[E], b[E];
+    double aa = 0.0, bb = 0.0, gr = 0.0, gi = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        a[e] = ga[sub + GS * e];
+        b[e] = gb[sub + GS * e];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        aa = fma(a[e].x, a[e].x, fma(a[e].y, a[e].y, aa));
+        bb = fma(b[e].x, b[e].x, fma(b[e].y, b[e].y, bb));
+        gr = fma(a[e].x, b[e].x, fma(a[e].y, b[e].y, gr));      // conj(a) * b
+        gi = fma(a[e].x, b[e].y, fma(-a[e].y, b[e].x, gi));
+    }
+    aa = group_sum<GS>(aa);
+    bb = group_sum<GS>(bb);
+    gr = group_sum<GS>(gr);
+    gi = group_sum<GS>(gi);
+    if (aa <= zero2 || bb <= zero2) return 0.0;
+    const double g2 = gr * gr + gi * gi;
+    const double ab = aa * bb;
+    const double ratio2 = g2 * fast_rcp(ab);
+    if (g2 == 0.0 || g2 <= tol2 * ab) return ratio2;
+    const double ig = fast_rsq(g2);
+    const double g = g2 * ig;
+    const double h = bb - aa;
+    const double w2 = fma(h, h, 4.0 * g2);
+    const double w = w2 * fast_rsq(w2);
+    double t = 2.0 * g * fast_rcp(fabs(h) + w);
+    t = h >= 0.0 ? t : -t;
+    const double c = fast_rsq(fma(t, t, 1.0));
+    const double s = c * t;
+    // a' = c a - sig b ; b' = conj(sig)... written with sig = s exp(-i phi), tau = c exp(-i phi):
+    //   a' = c a - sig b,  b' = s a + tau b
+    const double sr = s * gr * ig, si = -s * gi * ig;
+    const double tr = c * gr * ig, ti = -c * gi * ig;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        double2 na, nb;
+        na.x = fma(c, a[e].x, fma(-sr, b[e].x, si * b[e].y));
+        na.y = fma(c, a[e].y, fma(-sr, b[e].y, -si * b[e].x));
+        nb.x = fma(s, a[e].x, fma(tr, b[e].x, -ti * b[e].y));
+        nb.y = fma(s, a[e].y, fma(tr, b[e].y, ti * b[e].x));
+        ga[sub + GS * e] = na;
+        gb[sub + GS * e] = nb;
+    }
+    return ratio2;
+}
+
+template <int GS, int E, typename C>
+__device__ __forceinline__ int jacobi_sweeps_pad(C cols, int n, int max_sweeps, double tol, double* s_ratio, int tid,
+                                                 double zero2) {
+    const int grp = tid / GS, sub = tid % GS;
+    constexpr int ngroups = JAC_THREADS / GS;
+    const int np = n + (n & 1);      // padded to even; index np-1 == n is a bye when n is odd
+    const int md = np - 1;
+    const double tol2 = tol * tol;
+    int sweeps = 0;
+    bool done = (n < 2);
+    bool last = false;
+    while (!done && sweeps < max_sweeps) {
+        if (tid == 0) *s_ratio = 0.0;
+        __syncthreads();
+        double ratio = 0.0;
+        for (int r = 0; r < md; ++r) {
+            for (int p = grp; p < np / 2; p += ngroups) {
+                int i, j;
+                if (p == 0) {
+                    i = np - 1;
+                    j = r;
+                } else {
+                    i = r + p;
+                    i = i >= md ? i - md : i;
+                    j = r + md - p;
+                    j = j >= md ? j - md : j;
+                }
+                if (i < n && j < n) {
+                    const int lo = i < j ? i : j, hi = i < j ? j : i;
+                    const double rr = jacobi_pair_pad<GS, E>(cols.col(lo), cols.col(hi), sub, tol2, zero2);
+                    ratio = rr > ratio ? rr : ratio;
+                }
+            }
+            __syncthreads();
+        }
+        if (sub == 0 && ratio > 0.0) atomicMax((unsigned long long*)s_ratio, (unsigned long long)__double_as_longlong(ratio));
+        __syncthreads();
+        const double mx = *s_ratio;  // max over the sweep of the SQUARED cosine between column pairs
+        ++sweeps;
+        done = last || mx <= tol2;
+        last = mx < 1e-16;           // quadratic convergence: the next sweep is the final one
+        __syncthreads();
+    }
+    return done ? sweeps : -sweeps;
+}
+
+// all columns in one array of known address space (LDS when P is an LDS pointer after inlining)
+template <typename P>
+struct DenseCols {
+    P base;
+    int mp;
+    __device__ __forceinline__ P col(int j) const { return base + j * mp; }
+};
+
+template <int GS, typename C>
+__device__ __forceinline__ int jacobi_dispatch_e(C g, int E, int n, int max_sweeps, double tol, double* s_ratio, int tid,
+                                                 double zero2) {
+    switch (E) {
+        case 1: return jacobi_sweeps_pad<GS, 1>(g, n, max_sweeps, tol, s_ratio, tid, zero2);
+        case 2: return jacobi_sweeps_pad<GS, 2>(g, n, max_sweeps, tol, s_ratio, tid, zero2);
+        case 3: return jacobi_sweeps_pad<GS, 3>(g, n, max_sweeps, tol, s_ratio, tid, zero2);
+        case 4: return jacobi_sweeps_pad<GS, 4>(g, n, max_sweeps, tol, s_ratio, tid, zero2);
+        case 5: return jacobi_sweeps_pad<GS, 5>(g, n, max_sweeps, tol, s_ratio, tid, zero2);
+        case 6: return jacobi_sweeps_pad<GS, 6>(g, n, max_sweeps, tol, s_ratio, tid, zero2);
+        case 7: return jacobi_sweeps_pad<GS, 7>(g, n, max_sweeps, tol, s_ratio, tid, zero2);
+        default: return jacobi_sweeps_pad<GS, 8>(g, n, max_sweeps, tol, s_ratio, tid, zero2);
+    }
+}
+
 // ---- QR with column pivoting (modified Gram-Schmidt, R only) ---------------------------------------
 // Preconditioner of Drmac-Veselic type: G0 P = Q R, then Jacobi runs on X = R^H whose columns are graded
 // by the pivoting, which cuts the sweep count from ~18 to a few on Schmidt-type (graded) spectra.  Q is
@@ -137,11 +272,11 @@ __device__ __forceinline__ int jacobi_sweeps(double2* g, double2* __restrict__ v
 // back -- is exactly the isometry the caller asked for (it staged G0 = M^H or M accordingly).
 // Columns are not swapped physically: s_col[k] is the physical column of logical position k.
 template <int GS>
-__device__ __forceinline__ void qrcp_mgs(double2* __restrict__ g0, int m0, int n0, int r, double2* X, int ldx,
+__device__ __forceinline__ void qrcp_mgs(double2* __restrict__ g0, int m0, int n0, int r, const SplitCols X,
                                          int* s_col, double* s_cn2, double* s_piv, int tid) {
     const int grp = tid / GS, sub = tid % GS, lane = tid & 63, wave = tid >> 6;
     const int ngroups = JAC_THREADS / GS;
-    for (int idx = tid; idx < ldx * r; idx += JAC_THREADS) X[idx] = make_double2(0.0, 0.0);
+    for (int idx = tid; idx < X.mp * r; idx += JAC_THREADS) X.col(idx / X.mp)[idx % X.mp] = make_double2(0.0, 0.0);
     for (int k = grp; k < n0; k += ngroups) {
         double c = 0.0;
         for (int i = sub; i < m0; i += GS) {
@@ -183,9 +318,10 @@ __device__ __forceinline__ void qrcp_mgs(double2* __restrict__ g0, int m0, int n
             }
             if (bi != j)                             // the finished part of R moves with its column
                 for (int jj = lane; jj < j; jj += 64) {
-                    const double2 t = X[(int64_t)jj * ldx + j];
-                    X[(int64_t)jj * ldx + j] = X[(int64_t)jj * ldx + bi];
-                    X[(int64_t)jj * ldx + bi] = t;
+                    double2* xc = X.col(jj);
+                    const double2 t = xc[j];
+                    xc[j] = xc[bi];
+                    xc[bi] = t;
                 }
             if (lane == 0) {
                 const int t = s_col[j];
@@ -220,7 +356,7 @@ __device__ __forceinline__ void qrcp_mgs(double2* __restrict__ g0, int m0, int n
             pp = group_sum<GS>(pp);
             const double pn = sqrt(pp);
             if (k == j) {
-                if (sub == 0) X[(int64_t)j * ldx + j] = make_double2(pn, 0.0);
+                if (sub == 0) X.col(j)[j] = make_double2(pn, 0.0);
                 continue;
             }
             dr = group_sum<GS>(dr);
@@ -240,7 +376,7 @@ __device__ __forceinline__ void qrcp_mgs(double2* __restrict__ g0, int m0, int n
             c = group_sum<GS>(c);
             if (sub == 0) {
                 s_cn2[k] = c;
-                X[(int64_t)j * ldx + k] = make_double2(dr / pn, -di / pn);   // conj(r_jk), r_jk = q^H a
+                X.col(j)[k] = make_double2(dr / pn, -di / pn);   // conj(r_jk), r_jk = q^H a
             }
         }
         __syncthreads();
@@ -269,12 +405,60 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
     const bool qrcp = (D.flags & HTN_SVD_QRCP) != 0;
     double2* g;
     if (qrcp) {
-        // G0 (m0 x n0 = D.pad x D.m) at gglob; X = R^H (n0 x r = m x n) in LDS or in the Vj workspace
+        // G0 (m0 x n0 = D.pad x D.m) at gglob; X = R^H (n0 x r = m x n), leading dimension mp = GS * E (zero padded),
+        // in LDS when it fits, else in the Vj workspace (the planner reserves roundup(m, 64) * n elements there)
         const int m0 = D.pad;
-        g = in_lds ? (double2*)g_lds : v;
-        if (m0 <= 16 * JAC_MAXEL) qrcp_mgs<16>(gglob, m0, m, n, g, m, s_col, s_cn2, s_piv, tid);
-        else if (m0 <= 32 * JAC_MAXEL) qrcp_mgs<32>(gglob, m0, m, n, g, m, s_col, s_cn2, s_piv, tid);
-        else qrcp_mgs<64>(gglob, m0, m, n, g, m, s_col, s_cn2, s_piv, tid);
+        const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
+        const int E = (m + gsx - 1) / gsx;
+        const int mp = gsx * E;
+        // (keeping only the leading columns in LDS and the rest in global memory was measured SLOWER than
+        // all-global: the mixed case needs flat addressing, 4.4 ms vs 3.1 ms for a 107 x 107 block)
+        const bool x_lds = (int64_t)mp * n <= lds_elems;
+        const int nl = x_lds ? n : 0;
+        const SplitCols X = {(double2*)g_lds, v, nl, mp};
+        if (m0 <= 16 * JAC_MAXEL) qrcp_mgs<16>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid);
+        else if (m0 <= 32 * JAC_MAXEL) qrcp_mgs<32>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid);
+        else qrcp_mgs<64>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid);
+        {   // |X|_F^2 -> threshold for "numerically zero" columns
+            double f = 0.0;
+            for (int idx = tid; idx < mp * n; idx += JAC_THREADS) {
+                const double2 x = X.col(idx / mp)[idx % mp];
+                f += x.x * x.x + x.y * x.y;
+            }
+            f = wave_sum(f);
+            if (tid == 0) s_ratio = 0.0;
+            __syncthreads();
+            if (lane == 0) atomicAdd(&s_ratio, f);
+            __syncthreads();
+        }
+        const double zero2q = 1e-30 * s_ratio;
+        __syncthreads();
+        int swq;
+        if (x_lds) {        // everything in LDS: ds_* addressing
+            const DenseCols<double2*> dc = {(double2*)g_lds, mp};
+            if (gsx == 16) swq = jacobi_dispatch_e<16>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
+            else if (gsx == 32) swq = jacobi_dispatch_e<32>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
+            else swq = jacobi_dispatch_e<64>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
+        } else {            // everything in global memory (L2 resident): global_* addressing
+            const DenseCols<double2*> dc = {v, mp};
+            if (gsx == 16) swq = jacobi_dispatch_e<16>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
+            else if (gsx == 32) swq = jacobi_dispatch_e<32>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
+            else swq = jacobi_dispatch_e<64>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
+        }
+        __syncthreads();
+        // column norms + write back with the pivoting undone: row k of X is row s_col[k] of the result
+        for (int j = wave; j < n; j += nwaves) {
+            double sn = 0.0;
+            for (int i = lane; i < m; i += 64) {
+                const double2 x = X.col(j)[i];
+                sn += x.x * x.x + x.y * x.y;
+                gglob[(int64_t)j * m + s_col[i]] = x;
+            }
+            sn = wave_sum(sn);
+            if (lane == 0) S[D.s_off + j] = sqrt(sn);
+        }
+        if (tid == 0) info[blockIdx.x] = swq;
+        return;
     } else {
         // V = identity ; stage G into LDS when it fits
         if (accumulate)
@@ -313,8 +497,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
         for (int i = lane; i < m; i += 64) {
             const double2 x = g[(int64_t)j * m + i];
             s += x.x * x.x + x.y * x.y;
-            if (qrcp) gglob[(int64_t)j * m + s_col[i]] = x;
-            else if (in_lds) gglob[(int64_t)j * m + i] = x;
+            if (in_lds) gglob[(int64_t)j * m + i] = x;
         }
         s = wave_sum(s);
         if (lane == 0) S[D.s_off + j] = sqrt(s);

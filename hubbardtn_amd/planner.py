@@ -581,7 +581,7 @@ def plan_svd(tl: ThetaLayout, placement: str, qrcp: bool = True):
             transposed.append(placement != "right")
             accumulate.append(False)
             go += m0 * n0
-            vo += n0 * r
+            vo += ((n0 + 63) // 64 * 64) * r        # padded leading dimension of the kernel's R^H workspace
             so += r
             max_m = max(max_m, m0, n0)
             mm, kk = max(rows, cols), min(rows, cols)

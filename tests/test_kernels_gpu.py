@@ -166,7 +166,7 @@ def test_jacobi_svd_qr_preconditioned(hip_ops, shapes):
         W, _ = np.linalg.qr(_rand_z(rng, n0 * r).reshape(n0, r))
         s = 10.0 ** (-12 * np.arange(r) / max(r - 1, 1))
         mats.append((U * s) @ W.conj().T)
-        go, vo, so = go + m0 * n0, vo + n0 * r, so + r
+        go, vo, so = go + m0 * n0, vo + ((n0 + 63) // 64 * 64) * r, so + r      # v region: padded R^H workspace
     dG = hip_ops.to_device(np.concatenate([M.T.reshape(-1) for M in mats]))
     dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
     hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), max(max(s_) for s_ in shapes), 40, 1e-14, info)

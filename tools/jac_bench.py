@@ -28,7 +28,7 @@ def run(m0, n0, flags, reps=5):
     d_desc = ops.to_device(desc)
     src = ops.to_device(M.T.reshape(-1).copy())
     G = ops.empty_z(m0 * n0)
-    V = ops.zeros_z(max(n0 * n0, m0 * n0))
+    V = ops.zeros_z(((max(m0, n0) + 63) // 64 * 64) * max(m0, n0))
     S = ops.empty_f64(max(m0, n0))
     info = ops.empty_i32(1)
     ts = []
