@@ -41,6 +41,21 @@ SITE_OPS = {
     "cdagF": (1, +1, _mat({(1, 0): 1, (2, 1): SQ2})),               # c+ opening a term (c+ F)
     "c": (1, -1, _mat({(0, 1): SQ2, (1, 2): 1})),                   # c  closing a term
     "Fc": (1, -1, _mat({(0, 1): SQ2, (1, 2): -1})),                 # c  opening a term (F c)
+    # even operators of the exchange terms (src:426-428): spin as a rank-1 spherical tensor, on-site pairs
+    "S": (2, 0, _mat({(1, 1): sqrt(3.0) / 2})),
+    "pair_dag": (0, +2, _mat({(2, 0): 1})),                         # c+_up c+_dn
+    "pair": (0, -2, _mat({(0, 2): 1})),                             # c_dn c_up
+}
+
+# two-site term kinds -> channels (name, (dN, k) carried by the virtual level, opening op, pass-through op,
+# closing op, closing factor).  Factors are fixed by the dense checks of tests/test_host_cpu.py:
+#   hop  : coef * sum_s (c+_{i s} c_{j s} + h.c.)      nn  : coef * n_i n_j
+#   ss   : coef * S_i . S_j                             pair: coef * (D+_i D_j + h.c.),  D = c_dn c_up
+TERM_CHANNELS = {
+    "hop": (("hop+", (+1, 1), "cdagF", "F", "c", SQ2), ("hop-", (-1, 1), "Fc", "F", "cdag", -SQ2)),
+    "nn": (("nn", (0, 0), "n", "id", "n", 1.0),),
+    "ss": (("ss", (0, 2), "S", "id", "S", -sqrt(3.0)),),
+    "pair": (("pair+", (+2, 0), "pair_dag", "id", "pair", 1.0), ("pair-", (-2, 0), "pair", "id", "pair_dag", 1.0)),
 }
 
 
@@ -127,28 +142,32 @@ class MPOSite:
 
 
 def _build_mpo(nsites, onsite, pairs):
-    """onsite: {site: [(opname, coef)]}; pairs: list of (i, j, kind, coef) with i < j (0-based),
-    kind in {'hop', 'nn'}: 'hop' = coef * sum_s (c+_{i s} c_{j s} + h.c.), 'nn' = coef * n_i n_j.
-    Finite-state-machine MPO: level 0 = nothing applied ('start'), last = complete ('final'),
+    """onsite: {site: [(opname, coef)]}; pairs: list of (i, j, kind, coef) with i < j (0-based), kind in
+    TERM_CHANNELS.  Finite-state-machine MPO: level 0 = nothing applied ('start'), last = complete ('final'),
     one chain of levels per open two-site term (no compression, like `H += h`, src:439)."""
+    chan_def = {}
     chans = {b: [] for b in range(nsites + 1)}      # bond b sits to the right of site b-1
+    coefs = {}
     for (i, j, kind, coef) in pairs:
         if coef == 0.0:
             continue
-        subs = (("hop+", (+1, 1)), ("hop-", (-1, 1))) if kind == "hop" else (("nn", (0, 0)),)
-        for sub, q in subs:
+        coefs[(i, j, kind)] = coefs.get((i, j, kind), 0.0) + coef
+    for (i, j, kind), coef in coefs.items():
+        for (sub, q, op_open, op_pass, op_close, fac) in TERM_CHANNELS[kind]:
+            chan_def[(sub, i, j)] = (q, op_open, op_pass, op_close, fac * coef)
             for b in range(i + 1, j + 1):
-                chans[b].append(((sub, i, j), q))
+                chans[b].append((sub, i, j))
+
+    def levels(b):
+        if b == 0:
+            return [("start",)], [(0, 0)]
+        if b == nsites:
+            return [("final",)], [(0, 0)]
+        names = [("start",)] + chans[b] + [("final",)]
+        return names, [(0, 0)] + [chan_def[c][0] for c in chans[b]] + [(0, 0)]
+
     sites = []
     for s in range(nsites):
-        def levels(b):
-            if b == 0:
-                return [("start",)], [(0, 0)]
-            if b == nsites:
-                return [("final",)], [(0, 0)]
-            names = [("start",)] + [c[0] for c in chans[b]] + [("final",)]
-            qn = [(0, 0)] + [c[1] for c in chans[b]] + [(0, 0)]
-            return names, qn
         nl, ql = levels(s)
         nr, qr = levels(s + 1)
         il = {n: k for k, n in enumerate(nl)}
@@ -164,25 +183,34 @@ def _build_mpo(nsites, onsite, pairs):
         for name in nr:
             if name[0] in ("start", "final"):
                 continue
-            sub, i, j = name
-            if i == s:
-                ent.append((il[("start",)], ir[name], {"hop+": "cdagF", "hop-": "Fc", "nn": "n"}[sub], 1.0))
+            q, op_open, op_pass, op_close, c = chan_def[name]
+            if name[1] == s:
+                ent.append((il[("start",)], ir[name], op_open, 1.0))
             else:
-                ent.append((il[name], ir[name], "id" if sub == "nn" else "F", 1.0))
-        coefs = {(i, j, kind): c for (i, j, kind, c) in pairs}
+                ent.append((il[name], ir[name], op_pass, 1.0))
         for name in nl:
             if name[0] in ("start", "final"):
                 continue
-            sub, i, j = name
-            if j == s:
-                if sub == "hop+":
-                    ent.append((il[name], ir[("final",)], "c", coefs[(i, j, "hop")] * SQ2))
-                elif sub == "hop-":
-                    ent.append((il[name], ir[("final",)], "cdag", -coefs[(i, j, "hop")] * SQ2))
-                else:
-                    ent.append((il[name], ir[("final",)], "n", coefs[(i, j, "nn")]))
+            q, op_open, op_pass, op_close, c = chan_def[name]
+            if name[2] == s:
+                ent.append((il[name], ir[("final",)], op_close, c))
         sites.append(MPOSite(ql, qr, ent))
     return sites
+
+
+def _exchange(pairs, i, j, J):
+    """exchange integral J = U_ijji = U_ijij between orbitals i, j (src:445-451, 565-611, 668-696):
+         J sum_{s s'} c+_{i s} c+_{j s'} c_{i s'} c_{j s}  +  J (c+_{i up} c+_{i dn} c_{j dn} c_{j up} + h.c.)
+       = -J (2 S_i.S_j + n_i n_j / 2) + J (D+_i D_j + h.c.)        (Hund / Kanamori form).
+    The overall sign TensorKit's fermionic @tensor contraction gives J1 (src:427) cannot be checked without the
+    package; the reference's tests never switch J on.  Parity of this term against the reference: UNPINNED."""
+    if J == 0.0:
+        return
+    if i > j:
+        i, j = j, i
+    pairs.append((i, j, "ss", -2.0 * J))
+    pairs.append((i, j, "nn", -0.5 * J))
+    pairs.append((i, j, "pair", J))
 
 
 def hamiltonian(sim: Simulation, L: int):
@@ -190,8 +218,8 @@ def hamiltonian(sim: Simulation, L: int):
     if isinstance(sim, OB_Sim):
         if sim.period != 0:
             raise NotImplementedError("helix (period != 0) is outside the hot-path scope (SURVEY 8f)")
-        if any(x != 0.0 for x in sim.J) or sim.kwargs.get("U13", [0.0]) != [0.0]:
-            raise NotImplementedError("exchange / U13 terms are a 'next' row (SURVEY 8f.2)")
+        if sim.kwargs.get("U13", [0.0]) != [0.0]:
+            raise NotImplementedError("U13 terms are a 'next' row (SURVEY 8f.2)")
         onsite = {s: [("docc", sim.u[0]), ("n", -sim.mu)] for s in range(L)}          # src:424
         pairs = []
         for r, tr in enumerate(sim.t, start=1):                                       # src:437-440
@@ -200,12 +228,15 @@ def hamiltonian(sim: Simulation, L: int):
         for r in range(1, len(sim.u)):                                                # src:441-444
             for i in range(L - r):
                 pairs.append((i, i + r, "nn", sim.u[r]))
+        for r, Jr in enumerate(sim.J, start=1):                                       # src:445-451
+            for i in range(L - r):
+                _exchange(pairs, i, i + r, Jr)
         return _build_mpo(L, onsite, pairs)
     if isinstance(sim, MB_Sim):
         B = sim.bands
-        if np.any(sim.J != 0.0) or np.any(sim.U13 != 0.0):
-            raise NotImplementedError("multi-band exchange / U13 terms are a 'next' row (SURVEY 8f.2)")
-        t, u = sim.t, sim.u
+        if np.any(sim.U13 != 0.0):
+            raise NotImplementedError("multi-band U13 terms are a 'next' row (SURVEY 8f.2)")
+        t, u, Jm = sim.t, sim.u, sim.J
         n = L * B
         site = lambda band, cell: band + cell * B                                     # InfiniteStrip(B, T*B), src:491
         onsite = {}
@@ -238,5 +269,15 @@ def hamiltonian(sim: Simulation, L: int):
                     for bf in range(B):
                         add(site(bi, cell), site(bf, cell + r), "nn", M[bi, bf])                    # src:664
         pairs = [(i, j, kind, c) for (i, j, kind), c in sorted(acc.items()) if c != 0.0]
+        for cell in range(L):                                                         # Exchange_OS, src:565-615
+            for bi in range(B):
+                for bf in range(bi + 1, B):
+                    _exchange(pairs, site(bi, cell), site(bf, cell), 0.5 * (Jm[bi, bf] + Jm[bf, bi]))
+        for r in range(1, Jm.shape[1] // B):                                          # Exchange_IS, src:668-700
+            M = Jm[:, B * r:B * (r + 1)]
+            for cell in range(L - r):
+                for bi in range(B):
+                    for bf in range(B):
+                        _exchange(pairs, site(bi, cell), site(bf, cell + r), M[bi, bf])
         return _build_mpo(n, onsite, pairs)
     raise TypeError(f"unsupported simulation type {type(sim)}")

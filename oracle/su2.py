@@ -163,6 +163,13 @@ def site_operators():
     # annihilators as conjugate spinor (-a_dn, a_up)
     ops["c"] = (1, -1, reduce_site_operator([-a_dn, a_up], 1))                 # absorb side
     ops["Fc"] = (1, -1, reduce_site_operator([-F @ a_dn, F @ a_up], 1))        # emit side
+    # spin operator as a rank-1 spherical tensor (components q = +1, 0, -1) and on-site pair operators; all even
+    # under fermion parity, so they need no Jordan-Wigner string.  Used by the exchange terms (src:426-428, 445-451)
+    sp = a_up.T @ a_dn                          # S^+
+    sz = 0.5 * (a_up.T @ a_up - a_dn.T @ a_dn)
+    ops["S"] = (2, 0, reduce_site_operator([-sp / np.sqrt(2.0), sz, sp.T / np.sqrt(2.0)], 2))
+    ops["pair_dag"] = (0, +2, reduce_site_operator([a_up.T @ a_dn.T], 0))       # c+_up c+_dn
+    ops["pair"] = (0, -2, reduce_site_operator([a_dn @ a_up], 0))               # c_dn c_up
     return ops
 
 

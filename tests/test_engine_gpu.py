@@ -113,3 +113,15 @@ def test_reference_test_constants_within_their_own_tolerance(hip_ops):
         assert E / L > bethe[U]                          # open ends cost energy
         if U == 0.0:     # exact free-fermion energy of the L=64 open chain; truncation error only
             assert abs(E - ed.free_fermion_energy(L, L // 2, L // 2)) < 5e-3
+
+
+def test_exchange_and_polyacetylene_models_match_oracle(hip_ops):
+    """spin-1 (k = 2) and pair (dN = +-2) MPO levels through the HIP path vs the oracle on the same MPO:
+    one band with J, and the polyacetylene parameter set (examples/polyacetylene.jl:29-33)"""
+    H = models.hamiltonian(models.OB_Sim([1.0, 0.2], [4.0, 0.5], 0.0, [0.3, 0.1], 1, 1), 8)
+    _generic_oracle_vs_hip(hip_ops, H, 8, (8, 0), 40, 2, 5)
+    t = np.array([[0.000, 3.803, -0.548, 0.000], [3.803, 0.000, 2.977, -0.501]])
+    U = np.array([[10.317, 6.264, 0.000, 0.000], [6.264, 10.317, 6.162, 0.000]])
+    J = np.array([[0.000, 0.123, 0.000, 0.000], [0.123, 0.000, 0.113, 0.000]])
+    H = models.hamiltonian(models.MB_Sim(t, U, J, 1, 1, 2.5, 20), 4)
+    _generic_oracle_vs_hip(hip_ops, H, 8, (8, 0), 40, 2, 5)
