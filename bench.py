@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--L", type=int, default=64)
     ap.add_argument("--U", type=float, default=4.0)
     ap.add_argument("--chi", type=int, default=512)
+    ap.add_argument("--model", default="one_band", choices=["one_band", "one_band_nnn", "polyacetylene"],
+                    help="one_band = BASELINE configs[1] (default, the bench line); the others are extra measurements")
     ap.add_argument("--grow", type=str, default="16x8,32x4,64x4,128x2,256x2",
                     help="untimed growth schedule chi x sweeps (state preparation, loose Lanczos)")
     ap.add_argument("--grow-tol", type=float, default=1e-6)
@@ -110,8 +112,20 @@ def main():
         shard = (rank, world, allreduce)
     ops = HipOps(local)
     L, t, u = args.L, [1.0], [args.U]
-    sim = models.OB_Sim(t, u, 0.0, 1, 1, 2.0, 8)
-    mpo = models.hamiltonian(sim, L)
+    if args.model == "one_band":
+        sim = models.OB_Sim(t, u, 0.0, 1, 1, 2.0, 8)
+        mpo = models.hamiltonian(sim, L)
+    elif args.model == "one_band_nnn":          # examples/One_band.jl:25 hopping t = [1.0, 0.1] (BASELINE configs[4])
+        t = [1.0, 0.1]
+        sim = models.OB_Sim(t, u, 0.0, 1, 1, 2.0, 8)
+        mpo = models.hamiltonian(sim, L)
+    else:                                       # examples/polyacetylene.jl:29-33, L/2 cells of 2 bands
+        tm = np.array([[0.000, 3.803, -0.548, 0.000], [3.803, 0.000, 2.977, -0.501]])
+        Um = np.array([[10.317, 6.264, 0.000, 0.000], [6.264, 10.317, 6.162, 0.000]])
+        Jm = np.array([[0.000, 0.123, 0.000, 0.000], [0.123, 0.000, 0.113, 0.000]])
+        sim = models.MB_Sim(tm, Um, Jm, 1, 1, 2.5, 20)
+        mpo = models.hamiltonian(sim, L // 2)
+        args.no_cpu_baseline = True
     bonds, tens = mps.random_mps(L, (L, 0), 4, seed=1234)
     eng = engine.DMRG2(ops, mpo, bonds, tens, chi_full=16, lanczos_tol=args.lanczos_tol, shard=shard)
     t_start = time.perf_counter()
@@ -171,7 +185,7 @@ def main():
         "config": {"workload": f"one-band Hubbard chain L={L} U/t={args.U:g} half filling, fZ2xSU(2)xU(1), "
                                f"two-site DMRG sweep (2L-3={2 * L - 3} bond updates) at chi={args.chi} "
                                "(TensorKit dim units)",
-                   "L": L, "chi": args.chi, "krylovdim": eng.krylovdim, "lanczos_tol": args.lanczos_tol,
+                   "model": args.model, "L": L, "chi": args.chi, "krylovdim": eng.krylovdim, "lanczos_tol": args.lanczos_tol,
                    "parallelism": "sector-parallel apply x%d" % world},
         "energy_per_site": E / L,
         "max_bond_dim": max(eng.bond_dims()), "max_multiplets": max(b.multiplets for b in eng.bonds),
@@ -191,13 +205,13 @@ def main():
     # profiles/pmc_traffic.json for how it was collected and corrected
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"L{L}_chi{args.chi}")
-        if pmc and world == 1:
+        if pmc and world == 1 and args.model == "one_band":
             out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
             out["roofline"]["algorithmic_bytes_per_launch"] = sum(s.n_matvec * s.apply_bytes for s in stats) / max(tot_mv, 1)
     except Exception:
         pass
     log(json.dumps(out))
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "one_band":
         try:
             work = sum(s.n_matvec * s.apply_flops + s.svd_flops for s in stats) / args.steps
             cdt, cst, i0 = cpu_baseline(eng, L, t, u, args.lanczos_tol, args.cpu_bonds, log)

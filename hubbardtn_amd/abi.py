@@ -77,7 +77,7 @@ def load_library(path: str | None = None):
     lib.htn_dots_z.argtypes = [vp, i64, i32, vp, i64, vp, vp, vp]
     lib.htn_axpys_z.argtypes = [vp, vp, i64, i32, vp, f64, i64, vp]
     lib.htn_scale_inv_sqrt_z.argtypes = [vp, vp, vp, i64, vp]
-    lib.htn_jacobi_svd_z.argtypes = [vp, vp, vp, vp, i32, i32, i32, f64, vp, vp]
+    lib.htn_jacobi_svd_z.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f64, vp, vp]
     lib.htn_batched_copy_z.argtypes = [vp, vp, vp, vp, vp, i32, f64, vp]
     lib.htn_lanczos_scratch_elems.argtypes = [i32]
     lib.htn_lanczos_scratch_elems.restype = i64

@@ -1,4 +1,7 @@
 // batched Jacobi SVD + strided copy kernels (libhubbardtn_hip.so)
+#include <algorithm>
+#include <vector>
+
 #include "htn_common.h"
 
 // ----------------------------------------------------------------------------------------------
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
                                                             double* __restrict__ S,
                                                             const htn_svd_block* __restrict__ desc,
                                                             int max_sweeps, double tol, int* __restrict__ info,
-                                                            int lds_elems) {
+                                                            int lds_elems, int skip_large) {
     extern __shared__ double2 g_lds[];
     __shared__ double s_ratio;
     __shared__ double s_piv[2];
@@ -414,6 +417,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
         // (keeping only the leading columns in LDS and the rest in global memory was measured SLOWER than
         // all-global: the mixed case needs flat addressing, 4.4 ms vs 3.1 ms for a 107 x 107 block)
         const bool x_lds = (int64_t)mp * n <= lds_elems;
+        if (!x_lds && skip_large) return;             // handled by the multi-launch block-Jacobi path below
         const int nl = x_lds ? n : 0;
         const SplitCols X = {(double2*)g_lds, v, nl, mp};
         if (m0 <= 16 * JAC_MAXEL) qrcp_mgs<16>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid);
@@ -505,22 +509,274 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
     if (tid == 0) info[blockIdx.x] = sw;
 }
 
-extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc, int32_t n_blocks,
-                                int32_t max_m_host, int32_t max_sweeps, double tol, int32_t* info_dev,
-                                void* stream) {
+// ---- large blocks: block one-sided Jacobi over several CUs ---------------------------------------------
+// A block whose R^H does not fit one CU's LDS is VALU-bound on that CU (all n/2 pairs of a round on 16
+// waves).  Here the columns are cut into panels of w = 16 (8 for m > 256); one WORKGROUP orthogonalises one
+// PAIR of panels completely inside LDS (one or two inner sweeps), panel pairs of one round run on different
+// CUs, and rounds are separated by kernel boundaries (the only cross-CU synchronisation used: no in-kernel
+// grid barriers).  The host reads one number per block and outer sweep (max squared cosine) to stop.
+#ifndef JAC_PANEL_SMALL
+#define JAC_PANEL_SMALL 8
+#endif
+#define JAC_PANEL(mp) ((mp) <= 256 ? JAC_PANEL_SMALL : 8)
+struct JacPairItem {
+    int32_t blk, ci, ni, cj, nj, pad[3];
+};
+
+__global__ __launch_bounds__(JAC_THREADS) void k_qrcp_large(double2* __restrict__ G, double2* __restrict__ Vj,
+                                                            const htn_svd_block* __restrict__ desc,
+                                                            const int* __restrict__ large_ids, int* __restrict__ perm,
+                                                            double* __restrict__ zero2_out) {
+    __shared__ double s_piv[2];
+    __shared__ double s_f;
+    __shared__ int s_col[64 * JAC_MAXEL];
+    __shared__ double s_cn2[64 * JAC_MAXEL];
+    const htn_svd_block D = desc[large_ids[blockIdx.x]];
+    const int m = D.m, n = D.n, m0 = D.pad, tid = threadIdx.x, lane = tid & 63;
+    const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
+    const int mp = gsx * ((m + gsx - 1) / gsx);
+    double2* __restrict__ g0 = G + D.g_off;
+    const SplitCols X = {nullptr, Vj + D.v_off, 0, mp};
+    if (m0 <= 16 * JAC_MAXEL) qrcp_mgs<16>(g0, m0, m, n, X, s_col, s_cn2, s_piv, tid);
+    else if (m0 <= 32 * JAC_MAXEL) qrcp_mgs<32>(g0, m0, m, n, X, s_col, s_cn2, s_piv, tid);
+    else qrcp_mgs<64>(g0, m0, m, n, X, s_col, s_cn2, s_piv, tid);
+    double f = 0.0;
+    for (int idx = tid; idx < mp * n; idx += JAC_THREADS) {
+        const double2 x = X.glob[idx];
+        f += x.x * x.x + x.y * x.y;
+    }
+    f = wave_sum(f);
+    if (tid == 0) s_f = 0.0;
+    __syncthreads();
+    if (lane == 0) atomicAdd(&s_f, f);
+    __syncthreads();
+    if (tid == 0) zero2_out[blockIdx.x] = 1e-30 * s_f;
+    for (int i = tid; i < m; i += JAC_THREADS) perm[blockIdx.x * 64 * JAC_MAXEL + i] = s_col[i];
+}
+
+__global__ __launch_bounds__(JAC_THREADS) void k_jacobi_pairs(double2* __restrict__ Vj,
+                                                              const htn_svd_block* __restrict__ desc,
+                                                              const int* __restrict__ large_ids,
+                                                              const JacPairItem* __restrict__ items,
+                                                              const double* __restrict__ zero2,
+                                                              unsigned long long* __restrict__ ratio_bits,
+                                                              const int* __restrict__ done, double tol) {
+    extern __shared__ double2 g_lds[];
+    __shared__ double s_ratio;
+    const JacPairItem it = items[blockIdx.x];
+    if (done[it.blk]) return;
+    const htn_svd_block D = desc[large_ids[it.blk]];
+    const int m = D.m, tid = threadIdx.x;
+    const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
+    const int E = (m + gsx - 1) / gsx;
+    const int mp = gsx * E;
+    double2* __restrict__ X = Vj + D.v_off;
+    const int nc = it.ni + it.nj;
+    for (int idx = tid; idx < nc * mp; idx += JAC_THREADS) {
+        const int c = idx / mp, i = idx - c * mp;
+        const int col = c < it.ni ? it.ci + c : it.cj + (c - it.ni);
+        g_lds[idx] = X[(int64_t)col * mp + i];
+    }
+    __syncthreads();
+    const DenseCols<double2*> dc = {(double2*)g_lds, mp};
+    const double z2 = zero2[it.blk];
+    double first = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {       // at most two inner sweeps per visit
+        if (gsx == 16) jacobi_dispatch_e<16>(dc, E, nc, 1, tol, &s_ratio, tid, z2);
+        else if (gsx == 32) jacobi_dispatch_e<32>(dc, E, nc, 1, tol, &s_ratio, tid, z2);
+        else jacobi_dispatch_e<64>(dc, E, nc, 1, tol, &s_ratio, tid, z2);
+        const double r = s_ratio;
+        __syncthreads();
+        if (pass == 0) first = r;
+        if (r <= 1e-12) break;                   // (squared cosine) quadratic convergence: a second inner sweep
+                                                 // would only confirm; uniform: s_ratio is shared
+    }
+    for (int idx = tid; idx < nc * mp; idx += JAC_THREADS) {
+        const int c = idx / mp, i = idx - c * mp;
+        const int col = c < it.ni ? it.ci + c : it.cj + (c - it.ni);
+        X[(int64_t)col * mp + i] = g_lds[idx];
+    }
+    if (tid == 0 && first > 0.0) atomicMax(&ratio_bits[it.blk], (unsigned long long)__double_as_longlong(first));
+}
+
+__global__ __launch_bounds__(JAC_THREADS) void k_jacobi_finish(double2* __restrict__ G, const double2* __restrict__ Vj,
+                                                               double* __restrict__ S,
+                                                               const htn_svd_block* __restrict__ desc,
+                                                               const int* __restrict__ large_ids,
+                                                               const int* __restrict__ perm,
+                                                               const int* __restrict__ sweeps, int* __restrict__ info) {
+    const int b = large_ids[blockIdx.x];
+    const htn_svd_block D = desc[b];
+    const int m = D.m, n = D.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
+    const int mp = gsx * ((m + gsx - 1) / gsx);
+    const double2* __restrict__ X = Vj + D.v_off;
+    double2* __restrict__ g = G + D.g_off;
+    const int* __restrict__ pc = perm + blockIdx.x * 64 * JAC_MAXEL;
+    for (int j = wave; j < n; j += JAC_THREADS / 64) {
+        double sn = 0.0;
+        for (int i = lane; i < m; i += 64) {
+            const double2 x = X[(int64_t)j * mp + i];
+            sn += x.x * x.x + x.y * x.y;
+            g[(int64_t)j * m + pc[i]] = x;          // undo the pivoting: row k of X is row perm[k] of the result
+        }
+        sn = wave_sum(sn);
+        if (lane == 0) S[D.s_off + j] = sqrt(sn);
+    }
+    if (tid == 0) info[b] = sweeps[blockIdx.x];
+}
+
+// thread-local device scratch of the multi-launch path (grown on demand)
+struct JacScratch {
+    void* dev = nullptr;
+    size_t bytes = 0;
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+};
+static thread_local JacScratch g_js;
+
+static int js_reserve(size_t dev_bytes, size_t pin_bytes) {
+    if (dev_bytes > g_js.bytes) {
+        if (g_js.dev) HIP_TRY(hipFree(g_js.dev));
+        HIP_TRY(hipMalloc(&g_js.dev, dev_bytes * 2));
+        g_js.bytes = dev_bytes * 2;
+    }
+    if (pin_bytes > g_js.pinned_bytes) {
+        if (g_js.pinned) HIP_TRY(hipHostFree(g_js.pinned));
+        HIP_TRY(hipHostMalloc(&g_js.pinned, pin_bytes * 2));
+        g_js.pinned_bytes = pin_bytes * 2;
+    }
+    return 0;
+}
+
+extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc,
+                                const htn_svd_block* desc_host, int32_t n_blocks, int32_t max_m_host,
+                                int32_t max_sweeps, double tol, int32_t* info_dev, void* stream) {
     if (n_blocks <= 0) return 0;
     if (max_m_host > 64 * JAC_MAXEL) return fail_msg("htn_jacobi_svd_z: block taller than 512 rows");
+    hipStream_t st = (hipStream_t)stream;
     // dynamic LDS window for the matrix: 144 KiB leaves room for the static shared variables
     const int lds_elems = 9216;     // complex128 elements = 144 KiB
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_svd, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     lds_elems * (int)sizeof(double2)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_pairs, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    lds_elems * (int)sizeof(double2)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2),
-                       (hipStream_t)stream, (double2*)G, (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems);
+    // blocks that do not fit one CU's LDS go to the multi-launch block-Jacobi path (needs the host copy of desc)
+    std::vector<int> large;
+    if (desc_host)
+        for (int b = 0; b < n_blocks; ++b) {
+            const htn_svd_block& D = desc_host[b];
+            if (!(D.flags & HTN_SVD_QRCP) || D.n < 2) continue;
+            const int gsx = D.m <= 16 * JAC_MAXEL ? 16 : (D.m <= 32 * JAC_MAXEL ? 32 : 64);
+            const int mp = gsx * ((D.m + gsx - 1) / gsx);
+            if ((int64_t)mp * D.n > lds_elems) large.push_back(b);
+        }
+    hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2), st, (double2*)G,
+                       (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, large.empty() ? 0 : 1);
     HIP_TRY(hipGetLastError());
+    if (large.empty()) return 0;
+
+    const int nl = (int)large.size();
+    // panel-pair work lists, one per round of the round-robin tournament over the column panels of each block
+    std::vector<std::vector<JacPairItem>> rounds;
+    for (int li = 0; li < nl; ++li) {
+        const htn_svd_block& D = desc_host[large[li]];
+        const int gsx = D.m <= 16 * JAC_MAXEL ? 16 : (D.m <= 32 * JAC_MAXEL ? 32 : 64);
+        const int mp = gsx * ((D.m + gsx - 1) / gsx);
+        const int w = JAC_PANEL(mp);                       // 2 w columns of mp elements must fit the LDS window
+        const int nb = (D.n + w - 1) / w;
+        const int nbp = nb + (nb & 1);
+        if ((int)rounds.size() < nbp - 1) rounds.resize(nbp - 1);
+        for (int r = 0; r < nbp - 1; ++r)
+            for (int p = 0; p < nbp / 2; ++p) {
+                int a = p == 0 ? nbp - 1 : (r + p) % (nbp - 1);
+                int c = p == 0 ? r : (r + nbp - 1 - p) % (nbp - 1);
+                if (a >= nb || c >= nb) continue;
+                if (a > c) std::swap(a, c);
+                JacPairItem it = {li, a * w, std::min(w, D.n - a * w), c * w, std::min(w, D.n - c * w), {0, 0, 0}};
+                rounds[r].push_back(it);
+            }
+        if (nb == 1) {     // single panel: orthogonalise it against itself
+            if (rounds.empty()) rounds.resize(1);
+            JacPairItem it = {li, 0, D.n, 0, 0, {0, 0, 0}};
+            rounds[0].push_back(it);
+        }
+    }
+    size_t n_items = 0;
+    for (auto& r : rounds) n_items += r.size();
+    // device scratch layout: [large_ids | perm | zero2 | ratio | done | sweeps | items]
+    const size_t off_ids = 0, off_perm = off_ids + sizeof(int) * nl, off_zero = off_perm + sizeof(int) * nl * 64 * JAC_MAXEL;
+    const size_t off_ratio = (off_zero + sizeof(double) * nl + 7) / 8 * 8, off_done = off_ratio + 8 * nl;
+    const size_t off_sw = off_done + sizeof(int) * nl, off_items = (off_sw + sizeof(int) * nl + 31) / 32 * 32;
+    const size_t dev_bytes = off_items + sizeof(JacPairItem) * n_items;
+    if (js_reserve(dev_bytes, sizeof(JacPairItem) * n_items + 64 * nl + 64)) return 1;
+    char* d = (char*)g_js.dev;
+    int* d_ids = (int*)(d + off_ids);
+    int* d_perm = (int*)(d + off_perm);
+    double* d_zero = (double*)(d + off_zero);
+    unsigned long long* d_ratio = (unsigned long long*)(d + off_ratio);
+    int* d_done = (int*)(d + off_done);
+    int* d_sw = (int*)(d + off_sw);
+    JacPairItem* d_items = (JacPairItem*)(d + off_items);
+    // pinned staging: [items | ids | ratio(host) | done(host) | sweeps(host)]
+    char* h = (char*)g_js.pinned;
+    JacPairItem* h_items = (JacPairItem*)h;
+    int* h_ids = (int*)(h + sizeof(JacPairItem) * n_items);
+    double* h_ratio = (double*)((char*)h_ids + 16 * ((nl * 4 + 15) / 16));
+    int* h_done = (int*)(h_ratio + nl);
+    int* h_sw = h_done + nl;
+    std::vector<size_t> r_off(rounds.size());
+    {
+        size_t pos = 0;
+        for (size_t r = 0; r < rounds.size(); ++r) {
+            r_off[r] = pos;
+            for (auto& it : rounds[r]) h_items[pos++] = it;
+        }
+    }
+    for (int li = 0; li < nl; ++li) {
+        h_ids[li] = large[li];
+        h_done[li] = 0;
+        h_sw[li] = 0;
+    }
+    HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(JacPairItem) * n_items, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_ids, h_ids, sizeof(int) * nl, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_done, 0, sizeof(int) * nl, st));
+    hipLaunchKernelGGL(k_qrcp_large, dim3(nl), dim3(JAC_THREADS), 0, st, (double2*)G, (double2*)Vj, desc, d_ids, d_perm,
+                       d_zero);
+    std::vector<char> last(nl, 0);
+    bool all_done = false;
+    for (int sweep = 0; sweep < max_sweeps && !all_done; ++sweep) {
+        HIP_TRY(hipMemsetAsync(d_ratio, 0, 8 * nl, st));
+        for (size_t r = 0; r < rounds.size(); ++r)
+            if (!rounds[r].empty())
+                hipLaunchKernelGGL(k_jacobi_pairs, dim3((unsigned)rounds[r].size()), dim3(JAC_THREADS),
+                                   lds_elems * sizeof(double2), st, (double2*)Vj, desc, d_ids, d_items + r_off[r],
+                                   d_zero, d_ratio, d_done, tol);
+        HIP_TRY(hipMemcpyAsync(h_ratio, d_ratio, 8 * nl, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        all_done = true;
+        for (int li = 0; li < nl; ++li) {
+            if (h_done[li]) continue;
+            const double mx = h_ratio[li];
+            h_sw[li] += 1;
+            const bool dn = last[li] || mx <= tol * tol;
+            last[li] = mx < 1e-16;
+            h_done[li] = dn ? 1 : 0;
+            if (!dn) all_done = false;
+        }
+        HIP_TRY(hipMemcpyAsync(d_done, h_done, sizeof(int) * nl, hipMemcpyHostToDevice, st));
+    }
+    for (int li = 0; li < nl; ++li)
+        if (!h_done[li]) h_sw[li] = -h_sw[li];
+    HIP_TRY(hipMemcpyAsync(d_sw, h_sw, sizeof(int) * nl, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_jacobi_finish, dim3(nl), dim3(JAC_THREADS), 0, st, (double2*)G, (const double2*)Vj, S, desc,
+                       d_ids, d_perm, d_sw, info_dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));      // the pinned staging block is reused by the next call
     return 0;
 }
 

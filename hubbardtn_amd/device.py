@@ -140,8 +140,9 @@ class HipOps:
             self.event_log.append(("matvec_ms", ms.value, nmv.value))
         return eig.value, nmv.value, res.value
 
-    def jacobi_svd(self, G, Vj, S, desc_dev, nblocks, max_m, max_sweeps, tol, info):
-        abi.check(self.lib, self.lib.htn_jacobi_svd_z(self._p(G), self._p(Vj), self._p(S), self._p(desc_dev),
+    def jacobi_svd(self, G, Vj, S, desc_dev, nblocks, max_m, max_sweeps, tol, info, desc_host=None):
+        hp = C.c_void_p(desc_host.ctypes.data) if desc_host is not None else C.c_void_p(0)
+        abi.check(self.lib, self.lib.htn_jacobi_svd_z(self._p(G), self._p(Vj), self._p(S), self._p(desc_dev), hp,
                                                       nblocks, max_m, max_sweeps, float(tol), self._p(info),
                                                       self._stream()), "htn_jacobi_svd_z")
 

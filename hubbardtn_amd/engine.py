@@ -247,7 +247,7 @@ class DMRG2:
         S = ops.empty_f64(max(sp.s_size, 1))
         info = ops.empty_i32(max(nb, 1))
         ops.batched_copy(G, x, None, None, d_stage, nb, 1.0)
-        ops.jacobi_svd(G, Vj, S, d_desc, nb, sp.max_m, self.jacobi_max_sweeps, self.jacobi_tol, info)
+        ops.jacobi_svd(G, Vj, S, d_desc, nb, sp.max_m, self.jacobi_max_sweeps, self.jacobi_tol, info, desc_host=sp.desc)
         s_host = ops.to_host(S)
         info_h = ops.to_host(info)
         if nb and int(info_h[:nb].min()) < 0:

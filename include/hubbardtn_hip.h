@@ -127,7 +127,9 @@ int htn_lanczos_z(const htn_gemm_launch* stages_host, int32_t n_stages, int32_t 
  * the column norms go to S + s_off[i] and, if flags & HTN_SVD_ACCUMULATE, the n_i x n_i rotation J to
  * Vj + v_off[i] (ld = n_i).  The caller stages M or M^H (htn_batched_copy_z) so that the isometry the
  * sweep direction needs is the normalised G*J itself; the other factor is then a plain GEMM with M.
- * desc: device array of htn_svd_block; max_m_host = max_i m_i (<= 512 in this version).
+ * desc: device array of htn_svd_block, desc_host: the same array in host memory (may be NULL: then every block
+ * runs on ONE CU; with it, QRCP blocks larger than one CU's LDS use a multi-launch block-Jacobi over several CUs
+ * and the call synchronises the stream once per outer sweep); max_m_host = max_i m_i (<= 512 in this version).
  * info_dev[i] receives the sweep count (<0: not converged). */
 #define HTN_SVD_ACCUMULATE 1      /* flags: also accumulate the rotation J (else Vj is not touched) */
 #define HTN_SVD_QRCP 2            /* flags: the block at g_off is G0 (pad x m, ld = pad); pivoted-QR precondition it,
@@ -138,8 +140,9 @@ typedef struct {
     int32_t m, n;
     int32_t flags, pad;
 } htn_svd_block;        /* 40 bytes */
-int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc, int32_t n_blocks,
-                     int32_t max_m_host, int32_t max_sweeps, double tol, int32_t* info_dev, void* stream);
+int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc, const htn_svd_block* desc_host,
+                     int32_t n_blocks, int32_t max_m_host, int32_t max_sweeps, double tol, int32_t* info_dev,
+                     void* stream);
 
 /* dst(r x c, ldd) = op(src)(.., lds) with optional per-row / per-column real scaling:
  * generic batched strided copy used to (a) stage M or M^H into the Jacobi workspace and

@@ -133,7 +133,7 @@ class NumpyOps:
                 break
         return theta, nmv, res
 
-    def jacobi_svd(self, G, Vj, S, desc, nblocks, max_m, max_sweeps, tol, info):
+    def jacobi_svd(self, G, Vj, S, desc, nblocks, max_m, max_sweeps, tol, info, desc_host=None):
         for b in range(nblocks):
             d = desc[b]
             m, n = int(d["m"]), int(d["n"])

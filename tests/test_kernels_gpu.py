@@ -151,8 +151,10 @@ def test_jacobi_svd_matches_lapack(hip_ops, shapes, acc):
             assert np.abs(mats[i] @ j - gp).max() < 1e-13                     # G' = M J
 
 
-@pytest.mark.parametrize("shapes", [[(1, 1), (2, 3), (40, 40), (33, 57), (57, 33)], [(107, 107), (150, 93), (93, 150)]])
-def test_jacobi_svd_qr_preconditioned(hip_ops, shapes):
+@pytest.mark.parametrize("multi", [False, True])
+@pytest.mark.parametrize("shapes", [[(1, 1), (2, 3), (40, 40), (33, 57), (57, 33)], [(107, 107), (150, 93), (93, 150)],
+                                    [(230, 230), (60, 60), (300, 170), (129, 140)]])
+def test_jacobi_svd_qr_preconditioned(hip_ops, shapes, multi):
     """HTN_SVD_QRCP: G0 (m0 x n0) -> (right singular vectors of G0) x Sigma, n0 x min(m0, n0), rows in the
     ORIGINAL column order of G0; few sweeps on graded spectra"""
     rng = np.random.default_rng(8)
@@ -169,10 +171,13 @@ def test_jacobi_svd_qr_preconditioned(hip_ops, shapes):
         go, vo, so = go + m0 * n0, vo + ((n0 + 63) // 64 * 64) * r, so + r      # v region: padded R^H workspace
     dG = hip_ops.to_device(np.concatenate([M.T.reshape(-1) for M in mats]))
     dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
-    hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), max(max(s_) for s_ in shapes), 40, 1e-14, info)
+    # multi = True hands the host copy of the descriptors over: blocks larger than one CU's LDS then take the
+    # multi-launch block-Jacobi path (panel pairs on different CUs)
+    hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), max(max(s_) for s_ in shapes), 40, 1e-14, info,
+                       desc_host=desc if multi else None)
     Gp, S, inf = hip_ops.to_host(dG), hip_ops.to_host(dS), hip_ops.to_host(info)
     assert inf.min() >= 0, inf
-    assert inf.max() <= 10, inf                   # preconditioning keeps the sweep count small
+    assert inf.max() <= 12, inf                   # preconditioning keeps the sweep count small
     for i, (m0, n0) in enumerate(shapes):
         d = desc[i]
         r = min(m0, n0)

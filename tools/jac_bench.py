@@ -14,7 +14,7 @@ def rz(n):
     return rng.standard_normal(n) + 1j * rng.standard_normal(n)
 
 
-def run(m0, n0, flags, reps=5):
+def run(m0, n0, flags, reps=5, multi=False):
     r = min(m0, n0)
     U, _ = np.linalg.qr(rz(m0 * r).reshape(m0, r))
     W, _ = np.linalg.qr(rz(n0 * r).reshape(n0, r))
@@ -36,14 +36,14 @@ def run(m0, n0, flags, reps=5):
         G.copy_(src)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ops.jacobi_svd(G, V, S, d_desc, 1, max(m0, n0), 40, 1e-14, info)
+        ops.jacobi_svd(G, V, S, d_desc, 1, max(m0, n0), 40, 1e-14, info, desc_host=desc if multi else None)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     return min(ts), int(info.cpu()[0])
 
 
-for (m0, n0) in [(32, 32), (64, 64), (93, 93), (96, 96), (107, 107), (128, 128), (160, 160), (202, 202)]:
+for (m0, n0) in [(64, 64), (96, 96), (107, 107), (128, 128), (160, 160), (202, 202), (256, 256), (400, 400)]:
     a = run(m0, n0, abi.SVD_QRCP)
-    b = run(m0, n0, 0)
-    print(f"{m0}x{n0}: qrcp {a[0]:.3f} ms ({a[1]} sweeps)   plain {b[0]:.3f} ms ({b[1]} sweeps)", flush=True)
+    c = run(m0, n0, abi.SVD_QRCP, multi=True)
+    print(f"{m0}x{n0}: qrcp one-CU {a[0]:.3f} ms ({a[1]} sweeps)   multi-launch {c[0]:.3f} ms ({c[1]} sweeps)", flush=True)
