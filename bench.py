@@ -3,9 +3,10 @@
 
 One "step" = one full two-site DMRG sweep (MPSKit DMRG2 order, 2L-3 bond updates) of the
 one-band Hubbard chain L=64, U/t=4, half filling, SU(2)xU(1)xfZ2, at bond dimension chi
-(TensorKit `dim` units) after the state has been grown 64 -> ... -> chi in untimed sweeps.
-N=1 runs BASELINE.json configs[1] (chi=512); N>1 shards the effective-Hamiltonian apply over
-ranks (owner-computes over output tiles + RCCL all-reduce) on the same problem => strong scaling.
+(TensorKit `dim` units) after the state has been grown 16 -> ... -> chi in untimed sweeps.
+Default chi = 1024: the configuration BASELINE.json's `metric` is quoted on ("L=64 chi=1024"); it fits one
+GPU, so N=1 runs it, and N>1 shards the effective-Hamiltonian apply over ranks (owner-computes over output
+tiles + RCCL all-reduce) on the SAME problem => strong scaling.  `--chi 512` gives BASELINE configs[1].
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel k_grouped_gemm_z (H_eff
 apply launches inside the timed sweeps, HIP events on the launch stream); `cpu_baseline` times
@@ -31,13 +32,13 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--L", type=int, default=64)
     ap.add_argument("--U", type=float, default=4.0)
-    ap.add_argument("--chi", type=int, default=512)
+    ap.add_argument("--chi", type=int, default=1024)
     ap.add_argument("--model", default="one_band", choices=["one_band", "one_band_nnn", "polyacetylene"],
                     help="one_band = BASELINE configs[1] (default, the bench line); the others are extra measurements")
-    ap.add_argument("--grow", type=str, default="16x8,32x4,64x4,128x2,256x2",
+    ap.add_argument("--grow", type=str, default="16x8,32x4,64x4,128x2,256x2,512x2",
                     help="untimed growth schedule chi x sweeps (state preparation, loose Lanczos)")
     ap.add_argument("--grow-tol", type=float, default=1e-6)
     ap.add_argument("--profile", action="store_true", help="sync-bracketed per-stage host timers (perturbs timing)")

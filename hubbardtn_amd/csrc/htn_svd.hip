@@ -391,7 +391,8 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
                                                             double* __restrict__ S,
                                                             const htn_svd_block* __restrict__ desc,
                                                             int max_sweeps, double tol, int* __restrict__ info,
-                                                            int lds_elems, int skip_large) {
+                                                            int lds_elems, const int* __restrict__ large_slot,
+                                                            int* __restrict__ perm, double* __restrict__ zero2_out) {
     extern __shared__ double2 g_lds[];
     __shared__ double s_ratio;
     __shared__ double s_piv[2];
@@ -417,8 +418,8 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
         // (keeping only the leading columns in LDS and the rest in global memory was measured SLOWER than
         // all-global: the mixed case needs flat addressing, 4.4 ms vs 3.1 ms for a 107 x 107 block)
         const bool x_lds = (int64_t)mp * n <= lds_elems;
-        if (!x_lds && skip_large) return;             // handled by the multi-launch block-Jacobi path below
         const int nl = x_lds ? n : 0;
+        const int slot = (!x_lds && large_slot) ? large_slot[blockIdx.x] : -1;
         const SplitCols X = {(double2*)g_lds, v, nl, mp};
         if (m0 <= 16 * JAC_MAXEL) qrcp_mgs<16>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid);
         else if (m0 <= 32 * JAC_MAXEL) qrcp_mgs<32>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid);
@@ -437,6 +438,13 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
         }
         const double zero2q = 1e-30 * s_ratio;
         __syncthreads();
+        if (slot >= 0) {
+            // large block: only the pivoted QR happens here (concurrently with the small blocks' Jacobi); the
+            // sweeps run as multi-launch block-Jacobi (k_jacobi_pairs), k_jacobi_finish writes the result
+            if (tid == 0) zero2_out[slot] = zero2q;
+            for (int i = tid; i < m; i += JAC_THREADS) perm[slot * 64 * JAC_MAXEL + i] = s_col[i];
+            return;
+        }
         int swq;
         if (x_lds) {        // everything in LDS: ds_* addressing
             const DenseCols<double2*> dc = {(double2*)g_lds, mp};
@@ -522,37 +530,6 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
 struct JacPairItem {
     int32_t blk, ci, ni, cj, nj, pad[3];
 };
-
-__global__ __launch_bounds__(JAC_THREADS) void k_qrcp_large(double2* __restrict__ G, double2* __restrict__ Vj,
-                                                            const htn_svd_block* __restrict__ desc,
-                                                            const int* __restrict__ large_ids, int* __restrict__ perm,
-                                                            double* __restrict__ zero2_out) {
-    __shared__ double s_piv[2];
-    __shared__ double s_f;
-    __shared__ int s_col[64 * JAC_MAXEL];
-    __shared__ double s_cn2[64 * JAC_MAXEL];
-    const htn_svd_block D = desc[large_ids[blockIdx.x]];
-    const int m = D.m, n = D.n, m0 = D.pad, tid = threadIdx.x, lane = tid & 63;
-    const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
-    const int mp = gsx * ((m + gsx - 1) / gsx);
-    double2* __restrict__ g0 = G + D.g_off;
-    const SplitCols X = {nullptr, Vj + D.v_off, 0, mp};
-    if (m0 <= 16 * JAC_MAXEL) qrcp_mgs<16>(g0, m0, m, n, X, s_col, s_cn2, s_piv, tid);
-    else if (m0 <= 32 * JAC_MAXEL) qrcp_mgs<32>(g0, m0, m, n, X, s_col, s_cn2, s_piv, tid);
-    else qrcp_mgs<64>(g0, m0, m, n, X, s_col, s_cn2, s_piv, tid);
-    double f = 0.0;
-    for (int idx = tid; idx < mp * n; idx += JAC_THREADS) {
-        const double2 x = X.glob[idx];
-        f += x.x * x.x + x.y * x.y;
-    }
-    f = wave_sum(f);
-    if (tid == 0) s_f = 0.0;
-    __syncthreads();
-    if (lane == 0) atomicAdd(&s_f, f);
-    __syncthreads();
-    if (tid == 0) zero2_out[blockIdx.x] = 1e-30 * s_f;
-    for (int i = tid; i < m; i += JAC_THREADS) perm[blockIdx.x * 64 * JAC_MAXEL + i] = s_col[i];
-}
 
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_pairs(double2* __restrict__ Vj,
                                                               const htn_svd_block* __restrict__ desc,
@@ -675,10 +652,13 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
             const int mp = gsx * ((D.m + gsx - 1) / gsx);
             if ((int64_t)mp * D.n > lds_elems) large.push_back(b);
         }
-    hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2), st, (double2*)G,
-                       (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, large.empty() ? 0 : 1);
-    HIP_TRY(hipGetLastError());
-    if (large.empty()) return 0;
+    if (large.empty()) {
+        hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2), st, (double2*)G,
+                           (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)nullptr,
+                           (int*)nullptr, (double*)nullptr);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
 
     const int nl = (int)large.size();
     // panel-pair work lists, one per round of the round-robin tournament over the column panels of each block
@@ -708,14 +688,16 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     }
     size_t n_items = 0;
     for (auto& r : rounds) n_items += r.size();
-    // device scratch layout: [large_ids | perm | zero2 | ratio | done | sweeps | items]
-    const size_t off_ids = 0, off_perm = off_ids + sizeof(int) * nl, off_zero = off_perm + sizeof(int) * nl * 64 * JAC_MAXEL;
+    // device scratch layout: [large_ids | slot of every block | perm | zero2 | ratio | done | sweeps | items]
+    const size_t off_ids = 0, off_slot = off_ids + sizeof(int) * nl, off_perm = off_slot + sizeof(int) * n_blocks;
+    const size_t off_zero = off_perm + sizeof(int) * nl * 64 * JAC_MAXEL;
     const size_t off_ratio = (off_zero + sizeof(double) * nl + 7) / 8 * 8, off_done = off_ratio + 8 * nl;
     const size_t off_sw = off_done + sizeof(int) * nl, off_items = (off_sw + sizeof(int) * nl + 31) / 32 * 32;
     const size_t dev_bytes = off_items + sizeof(JacPairItem) * n_items;
-    if (js_reserve(dev_bytes, sizeof(JacPairItem) * n_items + 64 * nl + 64)) return 1;
+    if (js_reserve(dev_bytes, sizeof(JacPairItem) * n_items + 64 * nl + 4 * n_blocks + 128)) return 1;
     char* d = (char*)g_js.dev;
     int* d_ids = (int*)(d + off_ids);
+    int* d_slot = (int*)(d + off_slot);
     int* d_perm = (int*)(d + off_perm);
     double* d_zero = (double*)(d + off_zero);
     unsigned long long* d_ratio = (unsigned long long*)(d + off_ratio);
@@ -729,6 +711,9 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     double* h_ratio = (double*)((char*)h_ids + 16 * ((nl * 4 + 15) / 16));
     int* h_done = (int*)(h_ratio + nl);
     int* h_sw = h_done + nl;
+    int* h_slot = h_sw + nl;
+    for (int b = 0; b < n_blocks; ++b) h_slot[b] = -1;
+    for (int li = 0; li < nl; ++li) h_slot[large[li]] = li;
     std::vector<size_t> r_off(rounds.size());
     {
         size_t pos = 0;
@@ -744,9 +729,11 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     }
     HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(JacPairItem) * n_items, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_ids, h_ids, sizeof(int) * nl, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_slot, h_slot, sizeof(int) * n_blocks, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_done, 0, sizeof(int) * nl, st));
-    hipLaunchKernelGGL(k_qrcp_large, dim3(nl), dim3(JAC_THREADS), 0, st, (double2*)G, (double2*)Vj, desc, d_ids, d_perm,
-                       d_zero);
+    // one launch: small blocks run their whole SVD, large blocks their pivoted QR (different CUs, concurrently)
+    hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2), st, (double2*)G,
+                       (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)d_slot, d_perm, d_zero);
     std::vector<char> last(nl, 0);
     bool all_done = false;
     for (int sweep = 0; sweep < max_sweeps && !all_done; ++sweep) {
