@@ -271,9 +271,9 @@ class TaskList:
         self.blocks[key]["segs"].append((SEG_COPY, 0, 0, 1, OP_N, buf_b, b_off, ldb, OP_N, 0, alpha))
 
     def finalize(self):
-        nseg = sum(len(b["segs"]) for b in self.blocks.values())
-        segs = np.zeros(max(nseg, 1), dtype=SEG_DT)
-        tiles = []
+        """emit the htn_seg / htn_tile arrays (segment records per block, tiles cut with numpy grids)"""
+        seg_rows = []
+        tile_parts = []
         pos = 0
         flops = 0
         for b in self.blocks.values():
@@ -283,28 +283,38 @@ class TaskList:
                 merged[sg[:10]] = merged.get(sg[:10], 0.0) + sg[10]
             seglist = [(k_, a_) for k_, a_ in merged.items() if a_ != 0.0]
             seglist.sort(key=lambda t: t[0][0])          # GEMM segments first, COPY segments last
-            ncopy = sum(1 for k_, _ in seglist if k_[0] == SEG_COPY)
-            start = pos
+            ncopy = 0
             ksum = 0
             for (typ, buf_a, a_off, lda, op_a, buf_b, b_off, ldb, op_b, k), alpha in seglist:
-                s = segs[pos]
-                s["type"], s["buf_a"], s["a_off"], s["lda"], s["op_a"] = typ, buf_a, a_off, lda, op_a
-                s["buf_b"], s["b_off"], s["ldb"], s["op_b"], s["k"] = buf_b, b_off, ldb, op_b, k
-                s["alpha_re"], s["alpha_im"] = alpha.real, alpha.imag
-                pos += 1
-                ksum += k if typ == SEG_GEMM else 0
-            cnt = pos - start
-            flops += 8 * b["m"] * b["n"] * ksum
-            for r0 in range(0, b["m"], HTN_TILE):
-                for c0 in range(0, b["n"], HTN_TILE):
-                    tm, tn = min(HTN_TILE, b["m"] - r0), min(HTN_TILE, b["n"] - c0)
-                    tiles.append((tm * tn * (ksum + 1), b["off"], b["buf"], b["ld"], tm, tn, r0, c0, start, cnt, ncopy))
-        tiles.sort(key=lambda t: -t[0])      # longest first: hardware dispatch order = LPT schedule
-        tarr = np.zeros(max(len(tiles), 1), dtype=TILE_DT)
-        for i, t in enumerate(tiles):
-            (_, tarr[i]["c_off"], tarr[i]["buf_c"], tarr[i]["ldc"], tarr[i]["m"], tarr[i]["n"],
-             tarr[i]["row0"], tarr[i]["col0"], tarr[i]["seg_begin"], tarr[i]["seg_count"], tarr[i]["pad0"]) = t
-        return Tasks(tarr, len(tiles), segs[:max(pos, 1)], pos, flops)
+                alpha = complex(alpha)
+                seg_rows.append((a_off, b_off, buf_a, buf_b, lda, ldb, k, op_a, op_b, typ, alpha.real, alpha.imag))
+                if typ == SEG_GEMM:
+                    ksum += k
+                else:
+                    ncopy += 1
+            cnt = len(seglist)
+            m, n = b["m"], b["n"]
+            flops += 8 * m * n * ksum
+            r0 = np.arange(0, m, HTN_TILE, dtype=np.int64)
+            c0 = np.arange(0, n, HTN_TILE, dtype=np.int64)
+            R0, C0 = np.meshgrid(r0, c0, indexing="ij")
+            R0, C0 = R0.ravel(), C0.ravel()
+            TM, TN = np.minimum(HTN_TILE, m - R0), np.minimum(HTN_TILE, n - C0)
+            part = np.zeros(len(R0), dtype=TILE_DT)
+            part["c_off"], part["buf_c"], part["ldc"] = b["off"], b["buf"], b["ld"]
+            part["m"], part["n"], part["row0"], part["col0"] = TM, TN, R0, C0
+            part["seg_begin"], part["seg_count"], part["pad0"] = pos, cnt, ncopy
+            tile_parts.append((part, TM * TN * (ksum + 1)))
+            pos += cnt
+        segs = np.array(seg_rows, dtype=SEG_DT) if seg_rows else np.zeros(1, dtype=SEG_DT)
+        if tile_parts:
+            tarr = np.concatenate([p for p, _ in tile_parts])
+            work = np.concatenate([w for _, w in tile_parts])
+            tarr = tarr[np.argsort(-work, kind="stable")]     # longest first: hardware dispatch order = LPT schedule
+            ntiles = len(tarr)
+        else:
+            tarr, ntiles = np.zeros(1, dtype=TILE_DT), 0
+        return Tasks(np.ascontiguousarray(tarr), ntiles, segs, pos, flops)
 
 
 @dataclass
