@@ -523,6 +523,9 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
 // PAIR of panels completely inside LDS (one or two inner sweeps), panel pairs of one round run on different
 // CUs, and rounds are separated by kernel boundaries (the only cross-CU synchronisation used: no in-kernel
 // grid barriers).  The host reads one number per block and outer sweep (max squared cosine) to stop.
+#ifndef JAC_INNER
+#define JAC_INNER 1
+#endif
 #ifndef JAC_PANEL_SMALL
 #define JAC_PANEL_SMALL 8
 #endif
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_pairs(double2* __restric
     const DenseCols<double2*> dc = {(double2*)g_lds, mp};
     const double z2 = zero2[it.blk];
     double first = 0.0;
-    for (int pass = 0; pass < 2; ++pass) {       // at most two inner sweeps per visit
+    for (int pass = 0; pass < JAC_INNER; ++pass) {       // at most JAC_INNER inner sweeps per visit
         if (gsx == 16) jacobi_dispatch_e<16>(dc, E, nc, 1, tol, &s_ratio, tid, z2);
         else if (gsx == 32) jacobi_dispatch_e<32>(dc, E, nc, 1, tol, &s_ratio, tid, z2);
         else jacobi_dispatch_e<64>(dc, E, nc, 1, tol, &s_ratio, tid, z2);
