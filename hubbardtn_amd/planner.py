@@ -271,9 +271,9 @@ class TaskList:
         self.blocks[key]["segs"].append((SEG_COPY, 0, 0, 1, OP_N, buf_b, b_off, ldb, OP_N, 0, alpha))
 
     def finalize(self):
-        """emit the htn_seg / htn_tile arrays (segment records per block, tiles cut with numpy grids)"""
+        """emit the htn_seg / htn_tile arrays: segment records per block, then ALL tiles in one vectorised pass"""
         seg_rows = []
-        tile_parts = []
+        blk_rows = []            # (off, buf, ld, m, n, seg_begin, seg_count, ncopy, ksum)
         pos = 0
         flops = 0
         for b in self.blocks.values():
@@ -293,28 +293,30 @@ class TaskList:
                 else:
                     ncopy += 1
             cnt = len(seglist)
-            m, n = b["m"], b["n"]
-            flops += 8 * m * n * ksum
-            r0 = np.arange(0, m, HTN_TILE, dtype=np.int64)
-            c0 = np.arange(0, n, HTN_TILE, dtype=np.int64)
-            R0, C0 = np.meshgrid(r0, c0, indexing="ij")
-            R0, C0 = R0.ravel(), C0.ravel()
-            TM, TN = np.minimum(HTN_TILE, m - R0), np.minimum(HTN_TILE, n - C0)
-            part = np.zeros(len(R0), dtype=TILE_DT)
-            part["c_off"], part["buf_c"], part["ldc"] = b["off"], b["buf"], b["ld"]
-            part["m"], part["n"], part["row0"], part["col0"] = TM, TN, R0, C0
-            part["seg_begin"], part["seg_count"], part["pad0"] = pos, cnt, ncopy
-            tile_parts.append((part, TM * TN * (ksum + 1)))
+            flops += 8 * b["m"] * b["n"] * ksum
+            blk_rows.append((b["off"], b["buf"], b["ld"], b["m"], b["n"], pos, cnt, ncopy, ksum))
             pos += cnt
         segs = np.array(seg_rows, dtype=SEG_DT) if seg_rows else np.zeros(1, dtype=SEG_DT)
-        if tile_parts:
-            tarr = np.concatenate([p for p, _ in tile_parts])
-            work = np.concatenate([w for _, w in tile_parts])
-            tarr = tarr[np.argsort(-work, kind="stable")]     # longest first: hardware dispatch order = LPT schedule
-            ntiles = len(tarr)
-        else:
-            tarr, ntiles = np.zeros(1, dtype=TILE_DT), 0
-        return Tasks(np.ascontiguousarray(tarr), ntiles, segs, pos, flops)
+        if not blk_rows:
+            return Tasks(np.zeros(1, dtype=TILE_DT), 0, segs, pos, flops)
+        B = np.array(blk_rows, dtype=np.int64)
+        ntr = (B[:, 3] + HTN_TILE - 1) // HTN_TILE
+        ntc = (B[:, 4] + HTN_TILE - 1) // HTN_TILE
+        nt = ntr * ntc
+        bi = np.repeat(np.arange(len(B)), nt)                         # block index of every tile
+        first = np.repeat(np.cumsum(nt) - nt, nt)
+        loc = np.arange(int(nt.sum())) - first                        # tile index inside its block
+        r0 = (loc // ntc[bi]) * HTN_TILE
+        c0 = (loc % ntc[bi]) * HTN_TILE
+        tarr = np.zeros(len(bi), dtype=TILE_DT)
+        tarr["c_off"], tarr["buf_c"], tarr["ldc"] = B[bi, 0], B[bi, 1], B[bi, 2]
+        tm = np.minimum(HTN_TILE, B[bi, 3] - r0)
+        tn = np.minimum(HTN_TILE, B[bi, 4] - c0)
+        tarr["m"], tarr["n"], tarr["row0"], tarr["col0"] = tm, tn, r0, c0
+        tarr["seg_begin"], tarr["seg_count"], tarr["pad0"] = B[bi, 5], B[bi, 6], B[bi, 7]
+        work = tm * tn * (B[bi, 8] + 1)
+        tarr = tarr[np.argsort(-work, kind="stable")]                 # longest first: dispatch order = LPT schedule
+        return Tasks(np.ascontiguousarray(tarr), len(tarr), segs, pos, flops)
 
 
 @dataclass
