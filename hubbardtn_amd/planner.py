@@ -629,28 +629,35 @@ def truncate(svals: dict, chi_full=None, cutoff=0.0, weighting="sqrtdim", rel_fl
     (2S+1)-fold degenerate.
       cutoff   -> truncbelow(10^-svalue), src:1007-1010 (keep Schmidt values > cutoff)
       chi_full -> truncdim(D), src:1363-1365 (largest values while sum (2S+1) kept <= D)
+    Order at the cut: by sqrt(2S+1) * Schmidt value (= tilde value) for weighting 'sqrtdim', by the Schmidt value
+    for 'none'; ties broken by sector label then index, so kept sets are prefixes per sector.
     Returns (keep: c -> count, discarded weight, norm of the kept part)."""
-    smax = max((float(s[0]) for s in svals.values() if len(s)), default=0.0)
-    items = []
-    for c, s in svals.items():
-        d = c[1] + 1
-        sd = sqrt(d)
-        for i, v in enumerate(s):
-            v = float(v)
-            if v / sd <= cutoff or v <= rel_floor * smax:
-                continue
-            items.append((-(v if weighting == "sqrtdim" else v / sd), c, i, d))
-    items.sort()
-    keep = {c: 0 for c in svals}
-    tot = 0
-    for key, c, i, d in items:
-        if chi_full is not None and tot + d > chi_full and tot > 0:
-            break               # (the largest multiplet is always kept, even if wider than chi_full)
-        keep[c] += 1
-        tot += d
-    total = sum(float(np.sum(np.asarray(s, dtype=float) ** 2)) for s in svals.values())
-    kept = sum(float(np.sum(np.asarray(svals[c][:keep[c]], dtype=float) ** 2)) for c in svals)
-    return keep, (total - kept) / total if total > 0 else 0.0, sqrt(kept)
+    secs = sorted(svals)
+    if not secs:
+        return {}, 0.0, 0.0
+    vals = np.concatenate([np.asarray(svals[c], dtype=float) for c in secs])
+    lens = np.array([len(svals[c]) for c in secs])
+    sid = np.repeat(np.arange(len(secs)), lens)
+    idx = np.concatenate([np.arange(n) for n in lens]) if len(vals) else np.zeros(0, dtype=int)
+    dims = np.array([c[1] + 1 for c in secs], dtype=np.int64)[sid]
+    smax = float(vals.max()) if len(vals) else 0.0
+    schmidt = vals / np.sqrt(dims)
+    ok = (schmidt > cutoff) & (vals > rel_floor * smax)
+    key = vals if weighting == "sqrtdim" else schmidt
+    cand = np.nonzero(ok)[0]
+    order = cand[np.lexsort((idx[cand], sid[cand], -key[cand]))]       # key desc, then sector, then index
+    keep_n = len(order)
+    if chi_full is not None and keep_n:
+        tot = np.cumsum(dims[order])
+        over = np.nonzero(tot > chi_full)[0]
+        if len(over):
+            keep_n = max(int(over[0]), 1)          # (the largest multiplet is always kept, even if wider than chi_full)
+    kept = order[:keep_n]
+    counts = np.bincount(sid[kept], minlength=len(secs))
+    keep = {c: int(counts[i]) for i, c in enumerate(secs)}
+    total = float(np.sum(vals ** 2))
+    kept_w = float(np.sum(vals[kept] ** 2))
+    return keep, (total - kept_w) / total if total > 0 else 0.0, sqrt(kept_w)
 
 
 def plan_finalize(tl: ThetaLayout, sp: SvdPlan, order: dict, keep: dict, layA: SiteLayout, layB: SiteLayout,
