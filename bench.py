@@ -193,10 +193,16 @@ def main():
         "matvecs_per_sweep": tot_mv / args.steps,
         "max_trunc_weight": max(s.trunc_weight for s in stats),
         "host_plan_s_per_sweep": sum(s.t_plan for s in stats) / args.steps,
+        # host wall per stage; lanczos and svd end in a stream sync by construction, so their wall = GPU time + host
+        # work of the stage; plan/theta and env are enqueue-only unless --profile adds syncs
         "stage_s_per_sweep": {"plan+theta": sum(s.t_plan for s in stats) / args.steps,
                               "lanczos": sum(s.t_lanczos for s in stats) / args.steps,
                               "svd+truncate": sum(s.t_svd for s in stats) / args.steps,
-                              "env": sum(s.t_env for s in stats) / args.steps} if args.profile else None,
+                              "env": sum(s.t_env for s in stats) / args.steps, "synced": bool(args.profile)},
+        # SVD stage (LAPACK-equivalent flops / time, no roofline claim): 4 (4 m n^2 + 8 n^3) per block
+        "svd": {"lapack_equiv_gflop_per_sweep": sum(s.svd_flops for s in stats) / args.steps / 1e9,
+                "achieved_tflops": sum(s.svd_flops for s in stats) / max(sum(s.t_svd for s in stats), 1e-9) / 1e12,
+                "max_jacobi_sweeps": max(s.jacobi_sweeps for s in stats)},
         "roofline": {"bound": "mfma", "kernel": "k_grouped_gemm_z (H_eff apply)", "achieved": achieved,
                      "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F64_MFMA_TFLOPS,
                      "traffic": None, "launches": k_n, "avg_launch_us": (k_ms * 1e3 / k_n) if k_n else None,

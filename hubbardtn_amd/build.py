@@ -24,7 +24,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INC, *SRCS, "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3"] + os.environ.get("HTN_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-shared", "-I", INC, *SRCS, "-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

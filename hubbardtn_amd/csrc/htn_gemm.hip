@@ -43,7 +43,11 @@ struct Cursor {
 
 // move the cursor forward by `nslabs` K slabs over the flat slab sequence of the tile's GEMM segments
 __device__ __forceinline__ void advance(Cursor& c, int nslabs, const htn_seg* __restrict__ segs, int seg_begin,
-                                        int n_gemm) {
+                                        int n_gemm, bool presplit) {
+    if (presplit) {          // every GEMM segment is one slab (k <= 16): no descriptor reads needed to walk
+        c.s += nslabs;
+        return;
+    }
     while (nslabs > 0 && c.s < n_gemm) {
         const int K = segs[seg_begin + c.s].k;
         const int rem = (K - c.k0 + KB - 1) / KB;
@@ -58,11 +62,10 @@ __device__ __forceinline__ void advance(Cursor& c, int nslabs, const htn_seg* __
     }
 }
 
-__device__ __forceinline__ void load_slab(Slab& r, const BufTable& bufs, const htn_tile& T,
-                                          const htn_seg* __restrict__ segs, const Cursor& c, bool valid, int tq) {
+__device__ __forceinline__ void load_slab(Slab& r, const BufTable& bufs, const htn_tile& T, const htn_seg& S,
+                                          const Cursor& c, bool valid, int tq) {
     r.a[0] = r.a[1] = r.b[0] = r.b[1] = make_double2(0.0, 0.0);
     if (!valid) return;
-    const htn_seg S = segs[T.seg_begin + c.s];
     const double2* __restrict__ Ap = bufs.p[S.buf_a] + S.a_off;
     const double2* __restrict__ Bp = bufs.p[S.buf_b] + S.b_off;
     const int K = S.k;
@@ -150,29 +153,43 @@ __global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, cons
     d4 acc_re = {0.0, 0.0, 0.0, 0.0};
     d4 acc_im = {0.0, 0.0, 0.0, 0.0};
 
+    const bool presplit = T.pad[1] != 0;
+    // Cursor of this quad over the tile's flat slab sequence (quad q takes slabs q, q+4, q+8, ...).  The
+    // segment DESCRIPTOR of the slab after the one being fetched is loaded one round ahead, so the data loads
+    // of a round never wait for a descriptor (a cold 64-byte scalar load costs ~0.6 us on the critical path).
     Cursor cur = {0, 0};
-    advance(cur, q, segs, T.seg_begin, n_gemm);      // quad q takes slabs q, q+4, q+8, ... of the flat sequence
+    advance(cur, q, segs, T.seg_begin, n_gemm, presplit);
     bool valid = cur.s < n_gemm;
+    htn_seg Sd = {};            // never read a descriptor that does not exist (a tile may own zero segments)
+    if (valid) Sd = segs[T.seg_begin + cur.s];
     Slab regs;
-    load_slab(regs, bufs, T, segs, cur, valid, tq);
+    load_slab(regs, bufs, T, Sd, cur, valid, tq);
+    Cursor nxt = cur;
+    bool nvalid = false;
+    if (valid) {
+        advance(nxt, NQ, segs, T.seg_begin, n_gemm, presplit);
+        nvalid = nxt.s < n_gemm;
+    }
+    htn_seg Sn = {};
+    if (nvalid) Sn = segs[T.seg_begin + nxt.s];
     bool any = n_gemm > 0;
     while (any) {
-        int op_a = 0, op_b = 0, kleft = 0;
-        if (valid) {
-            const htn_seg& S = segs[T.seg_begin + cur.s];
-            op_a = S.op_a;
-            op_b = S.op_b;
-            kleft = S.k - cur.k0;
-        }
+        const int op_a = valid ? Sd.op_a : 0, op_b = valid ? Sd.op_b : 0;
+        const int kleft = valid ? Sd.k - cur.k0 : 0;
         store_slab(regs, lds, op_a, op_b, tq);
         __syncthreads();
         const bool cur_valid = valid;
-        // advance the cursor and issue the next slab's global loads before the MFMAs
+        // the prefetched descriptor becomes current: issue the next slab's global loads before the MFMAs
+        cur = nxt;
+        valid = nvalid;
+        Sd = Sn;
+        load_slab(regs, bufs, T, Sd, cur, valid, tq);
+        nvalid = false;
         if (valid) {
-            advance(cur, NQ, segs, T.seg_begin, n_gemm);
-            valid = cur.s < n_gemm;
+            nxt = cur;
+            advance(nxt, NQ, segs, T.seg_begin, n_gemm, presplit);
+            nvalid = nxt.s < n_gemm;
         }
-        load_slab(regs, bufs, T, segs, cur, valid, tq);
         if (cur_valid) {
             const int ksteps = kleft >= KB ? KB / 4 : (kleft + 3) >> 2;
             for (int ks = 0; ks < ksteps; ++ks) {
@@ -187,6 +204,10 @@ __global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, cons
                 acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_im, a_re, acc_im, 0, 0, 0);
             }
         }
+        // descriptor of the slab after next: issued AFTER the MFMA phase -- scalar loads share lgkmcnt with the LDS
+        // reads of the MFMA operands, so an earlier issue would stall the first MFMA on this cold load; here its
+        // latency hides behind the barrier and the next round's LDS staging
+        if (nvalid) Sn = segs[T.seg_begin + nxt.s];
         any = __syncthreads_or(valid ? 1 : 0) != 0;     // also fences LDS reuse
     }
     // ---- COPY segments: C += alpha * X tile, spread over the quads (each adds into its partial) ----

@@ -300,6 +300,22 @@ class TaskList:
         if not blk_rows:
             return Tasks(np.zeros(1, dtype=TILE_DT), 0, segs, pos, flops)
         B = np.array(blk_rows, dtype=np.int64)
+        if seg_rows:
+            # pre-split every GEMM segment into 16-deep K slabs (tile.pad1 = 1): the kernel's quads then walk the
+            # slab list without reading segment records, and fetch each slab's descriptor one round ahead
+            gem = segs["type"] == SEG_GEMM
+            nch = np.where(gem, (segs["k"] + 15) // 16, 1).astype(np.int64)
+            cum = np.concatenate([[0], np.cumsum(nch)])
+            rep = np.repeat(segs, nch)
+            k0 = (np.arange(len(rep)) - np.repeat(cum[:-1], nch)) * 16
+            g = rep["type"] == SEG_GEMM
+            rep["a_off"] += np.where(g, np.where(rep["op_a"] == OP_N, k0 * rep["lda"], k0), 0)
+            rep["b_off"] += np.where(g, np.where(rep["op_b"] == OP_N, k0, k0 * rep["ldb"]), 0)
+            rep["k"] = np.where(g, np.minimum(16, rep["k"] - k0), rep["k"])
+            B[:, 6] = cum[B[:, 5] + B[:, 6]] - cum[B[:, 5]]
+            B[:, 5] = cum[B[:, 5]]
+            segs = np.ascontiguousarray(rep)
+            pos = len(segs)
         ntr = (B[:, 3] + HTN_TILE - 1) // HTN_TILE
         ntc = (B[:, 4] + HTN_TILE - 1) // HTN_TILE
         nt = ntr * ntc
@@ -314,6 +330,7 @@ class TaskList:
         tn = np.minimum(HTN_TILE, B[bi, 4] - c0)
         tarr["m"], tarr["n"], tarr["row0"], tarr["col0"] = tm, tn, r0, c0
         tarr["seg_begin"], tarr["seg_count"], tarr["pad0"] = B[bi, 5], B[bi, 6], B[bi, 7]
+        tarr["pad1"] = 1
         work = tm * tn * (B[bi, 8] + 1)
         tarr = tarr[np.argsort(-work, kind="stable")]                 # longest first: dispatch order = LPT schedule
         return Tasks(np.ascontiguousarray(tarr), len(tarr), segs, pos, flops)

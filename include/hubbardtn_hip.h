@@ -40,7 +40,8 @@ extern "C" {
 
 /* One output tile (<= 32 x 32) of an output block.  The tile owns segs[seg_begin .. +seg_count)
  * and is WRITTEN (not accumulated): a tile with no segments stores zeros.  Within that range all
- * GEMM segments come first and the last pad[0] entries are the COPY segments. */
+ * GEMM segments come first and the last pad[0] entries are the COPY segments.  pad[1] = 1 promises that every
+ * GEMM segment of the tile has k <= 16 (one K slab): the kernel then walks the list without reading it. */
 typedef struct {
     int64_t c_off;      /* element offset of the BLOCK origin inside bufs[buf_c]   */
     int32_t buf_c;      /* index into the buffer table                              */
