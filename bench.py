@@ -179,7 +179,8 @@ def main():
     achieved = (k_fl / world) / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     tot_mv = sum(s.n_matvec for s in stats)
     out = {
-        "metric": "DMRG sweep time (s) + GS energy/site, 1-band Hubbard L=64 chi=%d" % args.chi,
+        "metric": ("DMRG sweep time (s) + GS energy/site, 1-band Hubbard L=%d chi=%d" % (L, args.chi)) if args.model != "polyacetylene"
+        else "DMRG sweep time (s) + GS energy/site, polyacetylene 2-band model %d sites chi=%d" % (L, args.chi),
         "value": sweep_s, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": sweep_s * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": "c128", "data": "synthetic",
