@@ -431,9 +431,13 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
                 f += x.x * x.x + x.y * x.y;
             }
             f = wave_sum(f);
-            if (tid == 0) s_ratio = 0.0;
+            if (lane == 0) s_cn2[wave] = f;          // fixed-order sum over the 16 waves: bit-reproducible
             __syncthreads();
-            if (lane == 0) atomicAdd(&s_ratio, f);
+            if (tid == 0) {
+                double t = 0.0;
+                for (int q = 0; q < JAC_THREADS / 64; ++q) t += s_cn2[q];
+                s_ratio = t;
+            }
             __syncthreads();
         }
         const double zero2q = 1e-30 * s_ratio;
@@ -491,9 +495,13 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
             f += x.x * x.x + x.y * x.y;
         }
         f = wave_sum(f);
-        if (tid == 0) s_ratio = 0.0;
+        if (lane == 0) s_cn2[wave] = f;              // fixed-order sum over the 16 waves: bit-reproducible
         __syncthreads();
-        if (lane == 0) atomicAdd(&s_ratio, f);
+        if (tid == 0) {
+            double t = 0.0;
+            for (int q = 0; q < JAC_THREADS / 64; ++q) t += s_cn2[q];
+            s_ratio = t;
+        }
         __syncthreads();
     }
     const double zero2 = 1e-30 * s_ratio;

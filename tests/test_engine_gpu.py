@@ -125,3 +125,23 @@ def test_exchange_and_polyacetylene_models_match_oracle(hip_ops):
     J = np.array([[0.000, 0.123, 0.000, 0.000], [0.123, 0.000, 0.113, 0.000]])
     H = models.hamiltonian(models.MB_Sim(t, U, J, 1, 1, 2.5, 20), 4)
     _generic_oracle_vs_hip(hip_ops, H, 8, (8, 0), 40, 2, 5)
+
+
+def test_runs_are_bit_reproducible(hip_ops):
+    """every reduction on the path has a fixed order (needed so that replicated ranks of the sharded apply take
+    identical host decisions): two runs from the same start agree bit for bit, including a block that takes the
+    multi-launch block-Jacobi path"""
+    def run():
+        bonds, tens = mps.random_mps(16, (16, 0), 12, 5)
+        eng = engine.DMRG2(hip_ops, models.hamiltonian(models.OB_Sim([1.0], [4.0]), 16), bonds, tens, chi_full=1000,
+                           lanczos_tol=1e-8)
+        Es = [eng.sweep()]
+        return Es, {b: {c: v.copy() for c, v in s.items()} for b, s in eng.spectra.items()}, eng
+    E1, S1, eng = run()
+    E2, S2, _ = run()
+    assert E1 == E2
+    for b in S1:
+        for c in S1[b]:
+            assert np.array_equal(S1[b][c], S2[b][c])
+    tl = engine.ThetaLayout.build(eng.bonds[7], eng.bonds[9])
+    assert max(min(tl.mats[c][1], tl.mats[c][2]) for c in tl.mids) > 96      # a block beyond one CU's LDS window
