@@ -21,8 +21,8 @@ __global__ void k(double* out, int iters, long long* cyc) {
 template <int NACC>
 void run(int waves_per_block, int blocks) {
     double* out; long long* cyc;
-    hipMalloc(&out, sizeof(double) * 1024 * 1024);
-    hipMalloc(&cyc, sizeof(long long) * 4096);
+    (void)hipMalloc(&out, sizeof(double) * 1024 * 1024);
+    (void)hipMalloc(&cyc, sizeof(long long) * 4096);
     const int iters = 2000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     k<NACC><<<blocks, 64 * waves_per_block>>>(out, 10, cyc);
