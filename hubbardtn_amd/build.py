@@ -24,7 +24,12 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3"] + os.environ.get("HTN_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-shared", "-I", INC, *SRCS, "-o", LIB]
+    # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs.  Without it the 256-thread kernels get AGPR
+    # accumulators whose loop-carried values are copied VGPR<->AGPR around every MFMA group (48 moves + a full
+    # pipeline drain per k-step in k_jacobi_pairs_gram: 200 instead of 64 cycles per MFMA).
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-mllvm", "-amdgpu-mfma-vgpr-form"] \
+        + os.environ.get("HTN_EXTRA_FLAGS", "").split() \
+        + ["-std=c++17", "-fPIC", "-shared", "-I", INC, *SRCS, "-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

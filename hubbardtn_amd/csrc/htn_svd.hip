@@ -587,6 +587,276 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_pairs(double2* __restric
     if (tid == 0 && first > 0.0) atomicMax(&ratio_bits[it.blk], (unsigned long long)__double_as_longlong(first));
 }
 
+// ---- panel-pair visit on the Gram matrix ---------------------------------------------------------------
+// The visit above rotates 2 w = 16 columns of mp rows 15 times in a row: each round is a chain of LDS reads,
+// dots over the column, a lane reduction, the rotation and the write back -- about 1.7 us, almost all of it
+// latency.  The same visit restated so that only ONE pass touches the long columns:
+//   (1) G = P^H P  (16 x 16, Hermitian) on v_mfma_f64_16x16x4_f64, the row range split over the 4 waves;
+//   (2) one cyclic sweep of two-sided Jacobi on G, 8 disjoint rotations per round, accumulating U (16 x 16);
+//       one thread per matrix element, no reductions, two workgroup barriers per round;
+//   (3) P <- P U on the MFMA pipe, written straight back to global.
+// In exact arithmetic this is the visit above (a one-sided rotation of the columns IS the two-sided rotation
+// of their Gram matrix).  In floating point G is re-formed from the columns at every visit, so rounding in
+// (2) only perturbs the rotation angles, never the orthogonality test: the stopping criterion is evaluated on
+// the exact Gram of the visit.  The pivot 2 x 2 block is updated with Rutishauser's formulas
+// (a' = a - t|g|, b' = b + t|g|, 0 off-diagonal), which keep the small diagonal entries of a graded Gram
+// matrix relatively accurate (Demmel & Veselic 1992); the remaining entries use the plain bilinear update.
+struct JacRot {
+    double jjr, jji;        // J[j][j]
+    double jpr, jpi;        // J[partner(j)][j]
+    double dnew;            // new diagonal entry of column j's pivot block
+    int flag, pad;
+};
+
+// partner of LDS column slot x in round r.  mode 0 (cross visit, 8 rounds): slot p of panel A meets slot
+// 8 + (p + r) % 8 of panel B -- every A-B pair exactly once.  mode 1 (intra visit, 7 rounds): round-robin
+// tournament inside each group of 8 slots.
+__device__ __forceinline__ int jg_partner(int x, int r, int mode) {
+    if (mode == 0) return x < 8 ? 8 + ((x + r) & 7) : ((x - r) & 7);
+    const int g = x & 8, k = x & 7;
+    if (k == 7) return g + r;
+    if (k == r) return g + 7;
+    int y = 2 * r - k + 7;
+    y = y >= 14 ? y - 14 : (y >= 7 ? y - 7 : y);
+    return g + y;
+}
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ double2 cmulc(double2 ac, double2 b) {      // conj(ac) * b
+    return make_double2(fma(ac.x, b.x, ac.y * b.y), fma(ac.x, b.y, -ac.y * b.x));
+}
+
+#define JG_LD 17
+__global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__ Vj,
+                                                           const htn_svd_block* __restrict__ desc,
+                                                           const int* __restrict__ large_ids,
+                                                           const JacPairItem* __restrict__ items,
+                                                           const double* __restrict__ zero2,
+                                                           unsigned long long* __restrict__ ratio_bits,
+                                                           const int* __restrict__ done, double tol, int inner) {
+    extern __shared__ double2 g_lds[];
+    __shared__ unsigned long long s_rbits;
+    __shared__ JacRot s_rot[16];
+    const JacPairItem it = items[blockIdx.x];
+    if (done[it.blk]) return;
+    const htn_svd_block D = desc[large_ids[it.blk]];
+    const int m = D.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
+    const int mp = gsx * ((m + gsx - 1) / gsx);
+    const int ldp = mp + 1;
+    double2* __restrict__ X = Vj + D.v_off;
+    const int mode = it.pad[0], nrounds = mode ? 7 : 8;
+    double2* P = g_lds;                              // [16][ldp]
+    double2* GU = g_lds + 16 * ldp;                  // G[2][16][17], U[2][16][17]; the Gram partials alias it
+    const double z2 = zero2[it.blk];
+    const double tol2 = tol * tol;
+    if (tid == 0) s_rbits = 0ull;
+    // ---- (0) columns -> LDS: 16 lanes per column, 256 contiguous bytes per request ----
+    {
+        const int c = tid >> 4, r = tid & 15;
+        const bool live = c < 8 ? c < it.ni : c - 8 < it.nj;      // slots 0..7: first panel, 8..15: second
+        const int col = c < 8 ? it.ci + c : it.cj + (c - 8);
+        const double2* __restrict__ src = X + (int64_t)(live ? col : 0) * mp;
+        double2* dst = P + c * ldp;
+        const int ne = mp >> 4;
+        for (int e0 = 0; e0 < ne; e0 += 8) {
+            double2 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int row = r + 16 * (e0 + e);
+                v[e] = (live && e0 + e < ne) ? src[row] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e0 + e < ne) dst[r + 16 * (e0 + e)] = v[e];
+        }
+    }
+    __syncthreads();
+    // ---- (1) Gram: lane (l15, l4) feeds P[4 ks + l4][l15] as A and as B operand ----
+    {
+        d4 g1 = {0.0, 0.0, 0.0, 0.0}, g2 = {0.0, 0.0, 0.0, 0.0}, mm = {0.0, 0.0, 0.0, 0.0};
+        const double2* pc = P + l15 * ldp + l4;
+        const int nit = mp >> 4;                     // k-steps of this wave: ks = wave + 4 it
+        double2 nxt = pc[4 * wave];
+        for (int it = 0; it < nit; ++it) {           // operand of the next step in flight during the 3 MFMAs
+            const double2 v = nxt;
+            if (it + 1 < nit) nxt = pc[4 * (wave + 4 * (it + 1))];
+            g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, v.x, g1, 0, 0, 0);
+            g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, v.y, g2, 0, 0, 0);
+            mm = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, v.y, mm, 0, 0, 0);      // M[a][b] = sum re_a im_b
+        }
+        double* part = (double*)GU + (wave * 64 + lane) * 8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            part[r] = g1[r] + g2[r];
+            part[4 + r] = mm[r];
+        }
+    }
+    __syncthreads();
+    const int ei = tid >> 4, ej = tid & 15;
+    {
+        // accumulator element (row = l4 + 4 reg, col = l15): G[i][j] sits in lane j + 16 (i & 3), reg i >> 2
+        const double* pa = (const double*)GU + (ej + 16 * (ei & 3)) * 8 + (ei >> 2);
+        const double* pb = (const double*)GU + (ei + 16 * (ej & 3)) * 8 + 4 + (ej >> 2);
+        double gr = 0.0, mij = 0.0, mji = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {               // fixed order: deterministic
+            gr += pa[w * 512];
+            mij += pa[w * 512 + 4];
+            mji += pb[w * 512];
+        }
+        __syncthreads();                            // partials consumed; the region becomes G / U
+        GU[ei * JG_LD + ej] = make_double2(gr, mij - mji);
+        GU[2 * 16 * JG_LD + ei * JG_LD + ej] = make_double2(ei == ej ? 1.0 : 0.0, 0.0);
+    }
+    __syncthreads();
+    // ---- convergence measure of this visit: max squared cosine over its column pairs (exact Gram) ----
+    {
+        double ratio = 0.0;
+        const bool vi = ei < 8 ? ei < it.ni : ei - 8 < it.nj, vj = ej < 8 ? ej < it.ni : ej - 8 < it.nj;
+        if (vi && vj && ei < ej && (mode ? (ei >> 3) == (ej >> 3) : (ei < 8 && ej >= 8))) {
+            const double dii = GU[ei * JG_LD + ei].x, djj = GU[ej * JG_LD + ej].x;
+            const double2 g = GU[ei * JG_LD + ej];
+            if (dii > z2 && djj > z2) ratio = fma(g.x, g.x, g.y * g.y) * fast_rcp(dii * djj);
+        }
+        // the measure only feeds thresholds: reduce its upper 32 bits (rounded up), one bpermute per step
+        unsigned key = ratio > 0.0 ? (unsigned)((unsigned long long)__double_as_longlong(ratio) >> 32) + 1u : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)key, off);
+            key = o > key ? o : key;
+        }
+        if (lane == 0 && key) atomicMax(&s_rbits, (unsigned long long)key << 32);
+    }
+    __syncthreads();
+    const unsigned long long first_bits = s_rbits;
+    if (__longlong_as_double((long long)first_bits) <= tol2) {     // nothing to rotate in this visit (uniform)
+        if (tid == 0 && first_bits) atomicMax(&ratio_bits[it.blk], first_bits);
+        return;
+    }
+    // ---- (2) two-sided Jacobi on G, U <- U J ----
+    int cur = 0;
+    for (int sw = 0; sw < inner; ++sw) {
+        for (int r = 0; r < nrounds; ++r) {
+            const double2* Gc = GU + cur * 16 * JG_LD;
+            const double2* Uc = GU + (2 + cur) * 16 * JG_LD;
+            double2* Gn = GU + (cur ^ 1) * 16 * JG_LD;
+            double2* Un = GU + (2 + (cur ^ 1)) * 16 * JG_LD;
+            if (tid < 8) {
+                int x;
+                if (mode == 0) x = tid;
+                else {
+                    const int k = tid & 3;
+                    x = r + k;
+                    x = k == 0 ? 7 : (x >= 7 ? x - 7 : x);
+                    x += 2 * (tid & 4);
+                }
+                const int y = jg_partner(x, r, mode);
+                const int lo = x < y ? x : y, hi = x < y ? y : x;
+                const bool live = (lo < 8 ? lo < it.ni : lo - 8 < it.nj) && (hi < 8 ? hi < it.ni : hi - 8 < it.nj);
+                JacRot A = {1.0, 0.0, 0.0, 0.0, 0.0, 0, 0}, B = A;
+                const double aa = Gc[lo * JG_LD + lo].x, bb = Gc[hi * JG_LD + hi].x;
+                const double2 g = Gc[lo * JG_LD + hi];                 // conj(a) . b
+                if (live && aa > z2 && bb > z2) {
+                    const double g2 = fma(g.x, g.x, g.y * g.y);
+                    if (g2 > 0.0 && g2 > tol2 * aa * bb) {
+                        // J = [[c, c q g], [-c q conj(g), c]], q = t / |g|: real diagonal, no phase division.
+                        // cos from cos(2 theta) = |h| / w runs in parallel with the reciprocal that gives q.
+                        const double h = bb - aa, ah = fabs(h);
+                        const double w2 = fma(h, h, 4.0 * g2);
+                        const double iw = fast_rsq(w2);
+                        const double w = w2 * iw;
+                        double q = 2.0 * fast_rcp(ah + w);
+                        q = h >= 0.0 ? q : -q;
+                        const double c2 = fma(0.5 * ah, iw, 0.5);
+                        const double c = c2 * fast_rsq(c2);
+                        const double cq = c * q;
+                        A = {c, 0.0, -cq * g.x, cq * g.y, aa - q * g2, 1, 0};
+                        B = {c, 0.0, cq * g.x, cq * g.y, bb + q * g2, 1, 0};
+                    }
+                }
+                s_rot[lo] = A;
+                s_rot[hi] = B;
+            }
+            __syncthreads();
+            {
+                const int ib = jg_partner(ei, r, mode), jb = jg_partner(ej, r, mode);
+                const JacRot Ri = s_rot[ei], Rj = s_rot[ej];
+                const double2 jjj = make_double2(Rj.jjr, Rj.jji), jpj = make_double2(Rj.jpr, Rj.jpi);
+                const double2 gij = Gc[ei * JG_LD + ej], gijb = Gc[ei * JG_LD + jb];
+                const double2 gibj = Gc[ib * JG_LD + ej], gibjb = Gc[ib * JG_LD + jb];
+                const double2 uij = Uc[ei * JG_LD + ej], uijb = Uc[ei * JG_LD + jb];
+                double2 t1 = cmul(gij, jjj), t2 = cmul(gijb, jpj);
+                const double2 Tij = make_double2(t1.x + t2.x, t1.y + t2.y);
+                t1 = cmul(gibj, jjj);
+                t2 = cmul(gibjb, jpj);
+                const double2 Tibj = make_double2(t1.x + t2.x, t1.y + t2.y);
+                t1 = cmulc(make_double2(Ri.jjr, Ri.jji), Tij);
+                t2 = cmulc(make_double2(Ri.jpr, Ri.jpi), Tibj);
+                double2 gn = make_double2(t1.x + t2.x, t1.y + t2.y);
+                if (Ri.flag) {
+                    if (ej == ei) gn = make_double2(Ri.dnew, 0.0);
+                    else if (ej == ib) gn = make_double2(0.0, 0.0);
+                }
+                t1 = cmul(uij, jjj);
+                t2 = cmul(uijb, jpj);
+                Gn[ei * JG_LD + ej] = gn;
+                Un[ei * JG_LD + ej] = make_double2(t1.x + t2.x, t1.y + t2.y);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // ---- (3) P <- P U, transposed product so that a lane's 16 neighbours write 256 contiguous bytes:
+    //      D[b][i] = sum_a U[a][b] P[i][a]:  A operand U[4 kk + l4][l15], B operand P[i0 + l15][4 kk + l4] ----
+    {
+        const double2* Uc = GU + (2 + cur) * 16 * JG_LD;
+        double ur[4], ui[4], nui[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double2 u = Uc[(4 * kk + l4) * JG_LD + l15];
+            ur[kk] = u.x;
+            ui[kk] = u.y;
+            nui[kk] = -u.y;
+        }
+        int colg[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = l4 + 4 * r;
+            colg[r] = b < 8 ? (b < it.ni ? it.ci + b : -1) : (b - 8 < it.nj ? it.cj + (b - 8) : -1);
+        }
+        const int nrt = mp >> 4;
+        const double2* pb = P + l4 * ldp + l15;
+        double2 pn[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) pn[kk] = wave < nrt ? pb[4 * kk * ldp + wave * 16] : make_double2(0.0, 0.0);
+        for (int rt = wave; rt < nrt; rt += 4) {
+            const int i0 = rt * 16;
+            double2 p[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) p[kk] = pn[kk];
+            if (rt + 4 < nrt) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) pn[kk] = pb[4 * kk * ldp + i0 + 64];
+            }
+            d4 ar = {0.0, 0.0, 0.0, 0.0}, ai = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                ar = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[kk], p[kk].x, ar, 0, 0, 0);
+                ai = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[kk], p[kk].y, ai, 0, 0, 0);
+                ar = __builtin_amdgcn_mfma_f64_16x16x4f64(nui[kk], p[kk].y, ar, 0, 0, 0);
+                ai = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[kk], p[kk].x, ai, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (colg[r] >= 0) X[(int64_t)colg[r] * mp + i0 + l15] = make_double2(ar[r], ai[r]);
+        }
+    }
+    if (tid == 0) atomicMax(&ratio_bits[it.blk], first_bits);
+}
+
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_finish(double2* __restrict__ G, const double2* __restrict__ Vj,
                                                                double* __restrict__ S,
                                                                const htn_svd_block* __restrict__ desc,
@@ -651,6 +921,8 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
                                     lds_elems * (int)sizeof(double2)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_pairs, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     lds_elems * (int)sizeof(double2)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_pairs_gram, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (16 * (64 * JAC_MAXEL + 1) + 4 * 16 * JG_LD) * (int)sizeof(double2)));
         attr_set = true;
     }
     // blocks that do not fit one CU's LDS go to the multi-launch block-Jacobi path (needs the host copy of desc)
@@ -673,11 +945,16 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
 
     const int nl = (int)large.size();
     // panel-pair work lists, one per round of the round-robin tournament over the column panels of each block
+    static const int use_gram = getenv("HTN_JAC_GRAM") ? atoi(getenv("HTN_JAC_GRAM")) : 1;
+    static const int gram_inner = getenv("HTN_JAC_GRAM_INNER") ? atoi(getenv("HTN_JAC_GRAM_INNER")) : 1;
     std::vector<std::vector<JacPairItem>> rounds;
+    std::vector<JacPairItem> intra;
+    int max_mp = 0;
     for (int li = 0; li < nl; ++li) {
         const htn_svd_block& D = desc_host[large[li]];
         const int gsx = D.m <= 16 * JAC_MAXEL ? 16 : (D.m <= 32 * JAC_MAXEL ? 32 : 64);
         const int mp = gsx * ((D.m + gsx - 1) / gsx);
+        max_mp = std::max(max_mp, mp);
         const int w = JAC_PANEL(mp);                       // 2 w columns of mp elements must fit the LDS window
         const int nb = (D.n + w - 1) / w;
         const int nbp = nb + (nb & 1);
@@ -691,12 +968,20 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
                 JacPairItem it = {li, a * w, std::min(w, D.n - a * w), c * w, std::min(w, D.n - c * w), {0, 0, 0}};
                 rounds[r].push_back(it);
             }
-        if (nb == 1) {     // single panel: orthogonalise it against itself
+        if (nb == 1 && !use_gram) {     // single panel: orthogonalise it against itself
             if (rounds.empty()) rounds.resize(1);
             JacPairItem it = {li, 0, D.n, 0, 0, {0, 0, 0}};
             rounds[0].push_back(it);
         }
+        if (use_gram)          // the pairs inside each panel, two panels per workgroup, once per outer sweep
+            for (int a = 0; a < nb; a += 2) {
+                const int c = a + 1;
+                JacPairItem it = {li, a * w, std::min(w, D.n - a * w), c < nb ? c * w : 0,
+                                  c < nb ? std::min(w, D.n - c * w) : 0, {1, 0, 0}};
+                intra.push_back(it);
+            }
     }
+    if (use_gram) rounds.insert(rounds.begin(), intra);
     size_t n_items = 0;
     for (auto& r : rounds) n_items += r.size();
     // device scratch layout: [large_ids | slot of every block | perm | zero2 | ratio | done | sweeps | items]
@@ -745,15 +1030,22 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     // one launch: small blocks run their whole SVD, large blocks their pivoted QR (different CUs, concurrently)
     hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2), st, (double2*)G,
                        (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)d_slot, d_perm, d_zero);
+    const size_t gram_lds_bytes = (size_t)(16 * (max_mp + 1) + 4 * 16 * JG_LD) * sizeof(double2);
     std::vector<char> last(nl, 0);
     bool all_done = false;
     for (int sweep = 0; sweep < max_sweeps && !all_done; ++sweep) {
         HIP_TRY(hipMemsetAsync(d_ratio, 0, 8 * nl, st));
         for (size_t r = 0; r < rounds.size(); ++r)
-            if (!rounds[r].empty())
-                hipLaunchKernelGGL(k_jacobi_pairs, dim3((unsigned)rounds[r].size()), dim3(JAC_THREADS),
-                                   lds_elems * sizeof(double2), st, (double2*)Vj, desc, d_ids, d_items + r_off[r],
-                                   d_zero, d_ratio, d_done, tol);
+            if (!rounds[r].empty()) {
+                if (use_gram)
+                    hipLaunchKernelGGL(k_jacobi_pairs_gram, dim3((unsigned)rounds[r].size()), dim3(256),
+                                       gram_lds_bytes, st, (double2*)Vj, desc, d_ids, d_items + r_off[r], d_zero,
+                                       d_ratio, d_done, tol, gram_inner);
+                else
+                    hipLaunchKernelGGL(k_jacobi_pairs, dim3((unsigned)rounds[r].size()), dim3(JAC_THREADS),
+                                       lds_elems * sizeof(double2), st, (double2*)Vj, desc, d_ids,
+                                       d_items + r_off[r], d_zero, d_ratio, d_done, tol);
+            }
         HIP_TRY(hipMemcpyAsync(h_ratio, d_ratio, 8 * nl, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         all_done = true;

@@ -43,7 +43,14 @@ def run(m0, n0, flags, reps=5, multi=False):
     return min(ts), int(info.cpu()[0])
 
 
-for (m0, n0) in [(64, 64), (96, 96), (107, 107), (128, 128), (160, 160), (202, 202), (256, 256), (400, 400)]:
+sizes = [(64, 64), (96, 96), (107, 107), (128, 128), (160, 160), (202, 202), (256, 256), (400, 400)]
+if len(sys.argv) > 1:       # e.g. `jac_bench.py 256x256 202x180`: multi-launch path only
+    for a in sys.argv[1:]:
+        m0, n0 = (int(x) for x in a.split("x"))
+        c = run(m0, n0, abi.SVD_QRCP, multi=True)
+        print(f"{m0}x{n0}: multi-launch {c[0]:.3f} ms ({c[1]} sweeps)", flush=True)
+    sys.exit(0)
+for (m0, n0) in sizes:
     a = run(m0, n0, abi.SVD_QRCP)
     c = run(m0, n0, abi.SVD_QRCP, multi=True)
     print(f"{m0}x{n0}: qrcp one-CU {a[0]:.3f} ms ({a[1]} sweeps)   multi-launch {c[0]:.3f} ms ({c[1]} sweeps)", flush=True)
