@@ -45,11 +45,50 @@ __device__ __forceinline__ double row_sum16(double v) {      // all-reduce insid
     return v;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {       // all-reduce over the 64 lanes
+// value of lane L (compile-time constant) as a wave-uniform scalar: two v_readlane_b32, no LDS crossbar trip
+template <int L>
+__device__ __forceinline__ double lane_bcast(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), L);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), L);
+    return __hiloint2double(hi, lo);
+}
+
+// all-reduce over the 64 lanes (call with the whole wave active).  The four row sums are combined as
+// (r0 + r1) + (r2 + r3) -- the order of the xor-16 / xor-32 butterfly this replaces, so results are
+// bit-identical to it -- but read with v_readlane instead of ds_bpermute: a bpermute round trip costs
+// ~120 cycles and a double needs two of them per butterfly step.
+__device__ __forceinline__ double wave_sum(double v) {
     v = row_sum16(v);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    const double a = lane_bcast<0>(v) + lane_bcast<16>(v);
+    const double b = lane_bcast<32>(v) + lane_bcast<48>(v);
+    return a + b;
+}
+
+// ---- cross-lane max of 64-bit keys (order-preserving bit patterns of non-negative doubles | tag) -------
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned long long row_max16_u64(unsigned long long v) {
+    v = umax64(v, dpp_u64<0xB1>(v));
+    v = umax64(v, dpp_u64<0x4E>(v));
+    v = umax64(v, dpp_u64<0x141>(v));
+    v = umax64(v, dpp_u64<0x140>(v));
     return v;
+}
+template <int L>
+__device__ __forceinline__ unsigned long long lane_bcast_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, L);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), L);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    v = row_max16_u64(v);
+    return umax64(umax64(lane_bcast_u64<0>(v), lane_bcast_u64<16>(v)),
+                  umax64(lane_bcast_u64<32>(v), lane_bcast_u64<48>(v)));
 }
 
 // ---- fast reciprocal / reciprocal square root: hardware seed + 2 Newton steps (full f64 accuracy for

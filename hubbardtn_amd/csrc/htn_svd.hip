@@ -24,9 +24,12 @@
 template <int GS>
 __device__ __forceinline__ double group_sum(double v) {      // all-reduce inside aligned groups of GS lanes
     v = row_sum16(v);
-    if (GS >= 32) v += __shfl_xor(v, 16, 64);
-    if (GS >= 64) v += __shfl_xor(v, 32, 64);
-    return v;
+    if (GS == 16) return v;
+    // row sums as wave-uniform scalars (v_readlane) instead of ds_bpermute butterflies; same summation order
+    const double a = lane_bcast<0>(v) + lane_bcast<16>(v);
+    const double b = lane_bcast<32>(v) + lane_bcast<48>(v);
+    if (GS == 32) return (threadIdx.x & 32) ? b : a;
+    return a + b;
 }
 
 template <int GS>
@@ -387,17 +390,338 @@ __device__ __forceinline__ void qrcp_mgs(double2* __restrict__ g0, int m0, int n
     __syncthreads();
 }
 
+// workgroup barrier that orders LDS traffic only (__syncthreads() also drains the vector-memory queue; the
+// panel loop below issues global stores of R entries in every step that nobody reads before the kernel ends)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---- panel-blocked pivoted QR for blocks that live in global memory ---------------------------------
+// qrcp_mgs above streams the whole trailing matrix through one CU once per COLUMN (268 MB for a 256 x 256
+// block: 3.8 ms at the ~70 GB/s one CU gets out of L2).  Here the trailing matrix is touched once per PANEL
+// of 16 columns:
+//   (a) window pivoting: the 16 remaining columns of largest (exactly recomputed) norm form the panel;
+//   (b) panel factorisation: one wave owns one panel column IN REGISTERS; 16 steps of modified Gram-Schmidt
+//       with greedy pivoting inside the panel, the pivot column broadcast through LDS; a pivot whose norm
+//       fell by more than 100x inside the panel is projected a second time ("twice is enough"), so the
+//       panel basis Q_p is orthonormal to rounding and (I - Q_p Q_p^H) below is a projector;
+//   (c) trailing update, one wave per chunk of 16 columns, on v_mfma_f64_16x16x4_f64:
+//       C = Q_p^H A (rows of R), A <- A - Q_p C, new column norms recomputed from the updated columns.
+// Between panels this is block MODIFIED Gram-Schmidt (every panel sees the updated trailing matrix), whose
+// R factor is backward stable like that of column MGS.  R entries are stored by PHYSICAL column index
+// (X[j][phys k] = conj(r_jk)), so nothing is ever swapped and the row permutation handed on is the identity.
+template <int EL>
+__device__ __forceinline__ void qrcp_blocked(double2* __restrict__ g0, int m0, int n0, int r,
+                                             double2* __restrict__ Xg, int mp, int* s_col, double* s_cn2,
+                                             double* s_piv, double2* Qn, int tid) {
+    __shared__ double s_pn[16];
+    __shared__ double2 s_r[16][17];      // the panel's own R block, [pivot step][owner wave]; flushed once per panel
+    __shared__ int s_pc[16];
+    __shared__ int s_pos[16];
+    __shared__ int s_nb;
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int m0p = (m0 + 15) & ~15, ldq = m0p + 1;
+    for (int idx = tid; idx < mp * r; idx += JAC_THREADS) Xg[idx] = make_double2(0.0, 0.0);
+    for (int k = wave; k < n0; k += JAC_THREADS / 64) {
+        double c = 0.0;
+        for (int i = lane; i < m0; i += 64) {
+            const double2 x = g0[(int64_t)k * m0 + i];
+            c += x.x * x.x + x.y * x.y;
+        }
+        c = wave_sum(c);
+        if (lane == 0) {
+            s_cn2[k] = c;
+            s_col[k] = k;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double f = 0.0;
+        for (int k = lane; k < n0; k += 64) f += s_cn2[k];
+        f = wave_sum(f);
+        if (lane == 0) s_piv[1] = 1e-30 * f;       // "numerically zero" threshold on squared norms
+    }
+    __syncthreads();
+    const double zero2 = s_piv[1];
+    bool stop = false;
+    int j0 = 0;
+    while (j0 < r && !stop) {
+        const int nbmax = r - j0 < 16 ? r - j0 : 16;
+        // ---- (a) window: the nbmax largest remaining columns move to logical positions j0 .. ----
+        if (wave == 0) {
+            int nb = 0;
+            for (int t = 0; t < nbmax; ++t) {
+                const int j = j0 + t;
+                // key = norm bits with the low 10 mantissa bits replaced by 1023 - k: one 64-bit max finds the
+                // largest norm, ties (to 2^-42 relative) going to the smallest position
+                unsigned long long key = 0ull;
+                for (int k = j + lane; k < n0; k += 64) {
+                    const unsigned long long kk =
+                        ((unsigned long long)__double_as_longlong(s_cn2[k]) & ~0x3FFull) | (unsigned long long)(1023 - k);
+                    key = kk > key ? kk : key;
+                }
+                key = wave_max_u64(key);
+                const int bi = 1023 - (int)(key & 0x3FFull);
+                const double best = s_cn2[bi];
+                if (best <= zero2) break;
+                if (lane == 0) {
+                    const int tc = s_col[j];
+                    s_col[j] = s_col[bi];
+                    s_col[bi] = tc;
+                    s_cn2[bi] = s_cn2[j];
+                    s_cn2[j] = best;
+                }
+                ++nb;
+            }
+            if (lane == 0) s_nb = nb;
+        }
+        __syncthreads();
+        int nb = s_nb;
+        if (nb == 0) break;                          // numerically rank deficient: remaining R rows are zero
+        if (nb < nbmax) stop = true;
+        // ---- (b) panel factorisation: wave u < nb owns logical column j0 + u in registers ----
+        const bool owner = wave < nb;
+        const int pc = owner ? s_col[j0 + wave] : 0;
+        double2 a[EL];
+        double cn = owner ? s_cn2[j0 + wave] : -1.0;
+        const double ns = cn;
+#pragma unroll
+        for (int e = 0; e < EL; ++e) {
+            const int i = lane + 64 * e;
+            a[e] = (owner && i < m0) ? g0[(int64_t)pc * m0 + i] : make_double2(0.0, 0.0);
+        }
+        if (!owner)                                   // unused panel positions project onto nothing
+            for (int i = lane; i < m0p; i += 64) Qn[wave * ldq + i] = make_double2(0.0, 0.0);
+        // no global store inside the step loop: a store keeps its source registers busy until it has left the
+        // memory pipeline, and the next step would wait for that (s_waitcnt vmcnt(0)) before reusing them
+        if (tid < 256) s_r[tid >> 4][tid & 15] = make_double2(0.0, 0.0);
+        if (lane == 0) s_pc[wave] = pc;
+        bool pending = owner;
+        int nb_eff = nb;
+        for (int t = 0; t < nb; ++t) {
+            if (lane == 0) s_pn[wave] = pending ? cn : -1.0;
+            lds_barrier();
+            unsigned long long key = 0ull;             // same packing, 4 tag bits: 15 - wave
+            {
+                const double v = s_pn[l15];
+                if (v >= 0.0) key = ((unsigned long long)__double_as_longlong(v) & ~0xFull) | (unsigned long long)(15 - l15);
+            }
+            key = row_max16_u64(key);
+            const int bu = 15 - (int)(key & 0xFull);
+            const double best = key ? s_pn[bu] : -1.0;
+            if (best <= zero2) {                      // the rest of the panel is numerically zero (uniform)
+                nb_eff = t;
+                stop = true;
+                break;
+            }
+            if (wave == bu) {
+                if (cn < 1e-4 * ns) {                 // second projection against the panel's earlier pivots
+                    for (int s2 = 0; s2 < t; ++s2) {
+                        double dr = 0.0, di = 0.0;
+                        const double2* qs = Qn + s2 * ldq + lane;
+#pragma unroll
+                        for (int e = 0; e < EL; ++e) {
+                            if (lane + 64 * e < m0p) {
+                                const double2 q = qs[64 * e];
+                                dr += q.x * a[e].x + q.y * a[e].y;
+                                di += q.x * a[e].y - q.y * a[e].x;
+                            }
+                        }
+                        dr = wave_sum(dr);
+                        di = wave_sum(di);
+#pragma unroll
+                        for (int e = 0; e < EL; ++e) {
+                            if (lane + 64 * e < m0p) {
+                                const double2 q = qs[64 * e];
+                                a[e].x -= dr * q.x - di * q.y;
+                                a[e].y -= dr * q.y + di * q.x;
+                            }
+                        }
+                        if (lane == 0) {
+                            const double2 old = s_r[s2][wave];
+                            s_r[s2][wave] = make_double2(old.x + dr, old.y - di);
+                        }
+                    }
+                    double c = 0.0;
+#pragma unroll
+                    for (int e = 0; e < EL; ++e) c += a[e].x * a[e].x + a[e].y * a[e].y;
+                    cn = wave_sum(c);
+                }
+                const double ipn = fast_rsq(cn);
+                const double pn = cn * ipn;
+#pragma unroll
+                for (int e = 0; e < EL; ++e) {
+                    const int i = lane + 64 * e;
+                    if (i < m0p) Qn[t * ldq + i] = make_double2(a[e].x * ipn, a[e].y * ipn);
+                }
+                if (lane == 0) {
+                    s_r[t][wave] = make_double2(pn, 0.0);
+                    s_pos[t] = pc;
+                }
+                pending = false;
+            }
+            lds_barrier();
+            if (pending) {
+                double dr = 0.0, di = 0.0;
+                const double2* qt = Qn + t * ldq + lane;       // zero padded up to m0p; a[e] is zero beyond m0
+#pragma unroll
+                for (int e = 0; e < EL; ++e) {
+                    if (lane + 64 * e < m0p) {
+                        const double2 q = qt[64 * e];
+                        dr += q.x * a[e].x + q.y * a[e].y;          // conj(q) * a
+                        di += q.x * a[e].y - q.y * a[e].x;
+                    }
+                }
+                dr = wave_sum(dr);
+                di = wave_sum(di);
+                double c = 0.0;
+#pragma unroll
+                for (int e = 0; e < EL; ++e) {
+                    if (lane + 64 * e < m0p) {
+                        const double2 q = qt[64 * e];
+                        a[e].x -= dr * q.x - di * q.y;
+                        a[e].y -= dr * q.y + di * q.x;
+                        c += a[e].x * a[e].x + a[e].y * a[e].y;
+                    }
+                }
+                cn = wave_sum(c);
+                if (lane == 0) s_r[t][wave] = make_double2(dr, -di);   // conj(r_tk)
+            }
+        }
+        __syncthreads();
+        if (nb_eff < nb) {                            // zero the positions the early exit left unwritten
+            for (int tt = nb_eff + wave; tt < nb; tt += JAC_THREADS / 64)
+                for (int i = lane; i < m0p; i += 64) Qn[tt * ldq + i] = make_double2(0.0, 0.0);
+        }
+        if (tid < nb_eff) s_col[j0 + tid] = s_pos[tid];
+        if (tid < 256 && (tid >> 4) < nb_eff && (tid & 15) < nb)      // rows of R before a column's own pivot step: 0
+            Xg[(int64_t)(j0 + (tid >> 4)) * mp + s_pc[tid & 15]] = s_r[tid >> 4][tid & 15];
+        __syncthreads();
+        // ---- (c) trailing update: wave per chunk of 16 logical columns ----
+        const int k_first = j0 + nb;
+        const int nchunks = (n0 - k_first + 15) >> 4;
+        const bool last_panel = stop || k_first >= r;
+        const int nks = m0p >> 2;
+        for (int ch = wave; ch < nchunks; ch += JAC_THREADS / 64) {
+            const int k = k_first + 16 * ch + l15;
+            const bool valid = k < n0;
+            const int pk = valid ? s_col[k] : 0;
+            double2* __restrict__ ak = g0 + (int64_t)pk * m0;
+            d4 cr = {0.0, 0.0, 0.0, 0.0}, ci = {0.0, 0.0, 0.0, 0.0};
+            const double2* qrow = Qn + l15 * ldq + l4;
+            double2 ring[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * u + l4;
+                ring[u] = (valid && u < nks && i < m0) ? ak[i] : make_double2(0.0, 0.0);
+            }
+            for (int ks0 = 0; ks0 < nks; ks0 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ks = ks0 + u;
+                    if (ks < nks) {
+                        const double2 b = ring[u];
+                        const int inx = 4 * (ks + 4) + l4;
+                        ring[u] = (valid && ks + 4 < nks && inx < m0) ? ak[inx] : make_double2(0.0, 0.0);
+                        const double2 qv = qrow[4 * ks];
+                        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.x, b.x, cr, 0, 0, 0);
+                        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.x, b.y, ci, 0, 0, 0);
+                        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.y, b.y, cr, 0, 0, 0);
+                        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-qv.y, b.x, ci, 0, 0, 0);
+                    }
+                }
+            }
+            // rows j0 + (l4 + 4 reg) of R, column k
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int t = l4 + 4 * reg;
+                if (valid && t < nb_eff) Xg[(int64_t)(j0 + t) * mp + pk] = make_double2(cr[reg], -ci[reg]);
+            }
+            if (last_panel) continue;                 // no later panel reads the trailing columns
+            double nrm = 0.0;
+            for (int i0 = 0; i0 < m0p; i0 += 16) {
+                double2 old[4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int i = i0 + l4 + 4 * reg;
+                    old[reg] = (valid && i < m0) ? ak[i] : make_double2(0.0, 0.0);
+                }
+                d4 dr = {0.0, 0.0, 0.0, 0.0}, di = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double2 qa = Qn[(l4 + 4 * kk) * ldq + i0 + l15];
+                    dr = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.x, cr[kk], dr, 0, 0, 0);
+                    di = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.x, ci[kk], di, 0, 0, 0);
+                    dr = __builtin_amdgcn_mfma_f64_16x16x4f64(-qa.y, ci[kk], dr, 0, 0, 0);
+                    di = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.y, cr[kk], di, 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int i = i0 + l4 + 4 * reg;
+                    if (valid && i < m0) {
+                        const double2 x = make_double2(old[reg].x - dr[reg], old[reg].y - di[reg]);
+                        ak[i] = x;
+                        nrm += x.x * x.x + x.y * x.y;
+                    }
+                }
+            }
+            nrm += __shfl_xor(nrm, 16, 64);      // over the 4 lanes (l4) that share a column
+            nrm += __shfl_xor(nrm, 32, 64);
+            if (valid && l4 == 0) s_cn2[k] = nrm;
+        }
+        __syncthreads();
+        j0 += nb;
+    }
+    __syncthreads();
+    for (int i = tid; i < n0; i += JAC_THREADS) s_col[i] = i;      // rows of X are physical columns already
+    __syncthreads();
+}
+
+// one workgroup per LARGE block (X = R^H does not fit the LDS window): pivoted QR only; the sweeps follow as
+// multi-launch block Jacobi.  Runs beside k_jacobi_svd (small blocks) on a forked stream.
+__global__ __launch_bounds__(JAC_THREADS) void k_qr_large(double2* __restrict__ G, double2* __restrict__ Vj,
+                                                          const htn_svd_block* __restrict__ desc,
+                                                          const int* __restrict__ large_ids, int* __restrict__ perm,
+                                                          double* __restrict__ zero2_out) {
+    extern __shared__ double2 g_lds[];
+    __shared__ double s_piv[2];
+    __shared__ int s_col[64 * JAC_MAXEL];
+    __shared__ double s_cn2[64 * JAC_MAXEL];
+    const htn_svd_block D = desc[large_ids[blockIdx.x]];
+    const int m = D.m, n = D.n, m0 = D.pad, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
+    const int mp = gsx * ((m + gsx - 1) / gsx);
+    double2* __restrict__ X = Vj + D.v_off;
+    if (m0 <= 256) qrcp_blocked<4>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid);
+    else qrcp_blocked<8>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid);
+    // |X|_F^2 -> threshold for "numerically zero" columns (fixed-order sums: bit-reproducible)
+    double f = 0.0;
+    for (int idx = tid; idx < mp * n; idx += JAC_THREADS) {
+        const double2 x = X[idx];
+        f += x.x * x.x + x.y * x.y;
+    }
+    f = wave_sum(f);
+    if (lane == 0) s_cn2[wave] = f;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int q = 0; q < JAC_THREADS / 64; ++q) t += s_cn2[q];
+        zero2_out[blockIdx.x] = 1e-30 * t;
+    }
+    for (int i = tid; i < m; i += JAC_THREADS) perm[blockIdx.x * 64 * JAC_MAXEL + i] = s_col[i];
+}
+
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict__ G, double2* __restrict__ Vj,
                                                             double* __restrict__ S,
                                                             const htn_svd_block* __restrict__ desc,
                                                             int max_sweeps, double tol, int* __restrict__ info,
-                                                            int lds_elems, const int* __restrict__ large_slot,
-                                                            int* __restrict__ perm, double* __restrict__ zero2_out) {
+                                                            int lds_elems, const int* __restrict__ large_slot) {
     extern __shared__ double2 g_lds[];
     __shared__ double s_ratio;
     __shared__ double s_piv[2];
     __shared__ int s_col[64 * JAC_MAXEL];
     __shared__ double s_cn2[64 * JAC_MAXEL];
+    if (large_slot && large_slot[blockIdx.x] >= 0) return;      // k_qr_large + block Jacobi own this block
     const htn_svd_block D = desc[blockIdx.x];
     const int m = D.m, n = D.n;
     double2* __restrict__ gglob = G + D.g_off;
@@ -419,7 +743,6 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
         // all-global: the mixed case needs flat addressing, 4.4 ms vs 3.1 ms for a 107 x 107 block)
         const bool x_lds = (int64_t)mp * n <= lds_elems;
         const int nl = x_lds ? n : 0;
-        const int slot = (!x_lds && large_slot) ? large_slot[blockIdx.x] : -1;
         const SplitCols X = {(double2*)g_lds, v, nl, mp};
         if (m0 <= 16 * JAC_MAXEL) qrcp_mgs<16>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid);
         else if (m0 <= 32 * JAC_MAXEL) qrcp_mgs<32>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid);
@@ -442,13 +765,6 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
         }
         const double zero2q = 1e-30 * s_ratio;
         __syncthreads();
-        if (slot >= 0) {
-            // large block: only the pivoted QR happens here (concurrently with the small blocks' Jacobi); the
-            // sweeps run as multi-launch block-Jacobi (k_jacobi_pairs), k_jacobi_finish writes the result
-            if (tid == 0) zero2_out[slot] = zero2q;
-            for (int i = tid; i < m; i += JAC_THREADS) perm[slot * 64 * JAC_MAXEL + i] = s_col[i];
-            return;
-        }
         int swq;
         if (x_lds) {        // everything in LDS: ds_* addressing
             const DenseCols<double2*> dc = {(double2*)g_lds, mp};
@@ -638,7 +954,6 @@ __global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__
                                                            const int* __restrict__ done, double tol, int inner) {
     extern __shared__ double2 g_lds[];
     __shared__ unsigned long long s_rbits;
-    __shared__ JacRot s_rot[16];
     const JacPairItem it = items[blockIdx.x];
     if (done[it.blk]) return;
     const htn_svd_block D = desc[large_ids[it.blk]];
@@ -721,14 +1036,8 @@ __global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__
             const double2 g = GU[ei * JG_LD + ej];
             if (dii > z2 && djj > z2) ratio = fma(g.x, g.x, g.y * g.y) * fast_rcp(dii * djj);
         }
-        // the measure only feeds thresholds: reduce its upper 32 bits (rounded up), one bpermute per step
-        unsigned key = ratio > 0.0 ? (unsigned)((unsigned long long)__double_as_longlong(ratio) >> 32) + 1u : 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned o = (unsigned)__shfl_xor((int)key, off);
-            key = o > key ? o : key;
-        }
-        if (lane == 0 && key) atomicMax(&s_rbits, (unsigned long long)key << 32);
+        const unsigned long long key = wave_max_u64((unsigned long long)__double_as_longlong(ratio));
+        if (lane == 0 && key) atomicMax(&s_rbits, key);
     }
     __syncthreads();
     const unsigned long long first_bits = s_rbits;
@@ -737,6 +1046,13 @@ __global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__
         return;
     }
     // ---- (2) two-sided Jacobi on G, U <- U J ----
+    // One thread per element (i, j).  It needs the rotation of i's pair (row operation) and of j's pair (column
+    // operation) and computes both itself from the pivot entries -- 256-fold redundant arithmetic, but the
+    // round is then a single chain [12 LDS reads -> two interleaved rotations -> update -> write] with ONE
+    // barrier (G and U are double buffered), instead of [8 lanes rotate] barrier [256 lanes apply] barrier.
+    unsigned livemask = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) livemask |= (unsigned)(q < 8 ? q < it.ni : q - 8 < it.nj) << q;
     int cur = 0;
     for (int sw = 0; sw < inner; ++sw) {
         for (int r = 0; r < nrounds; ++r) {
@@ -744,67 +1060,66 @@ __global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__
             const double2* Uc = GU + (2 + cur) * 16 * JG_LD;
             double2* Gn = GU + (cur ^ 1) * 16 * JG_LD;
             double2* Un = GU + (2 + (cur ^ 1)) * 16 * JG_LD;
-            if (tid < 8) {
-                int x;
-                if (mode == 0) x = tid;
-                else {
-                    const int k = tid & 3;
-                    x = r + k;
-                    x = k == 0 ? 7 : (x >= 7 ? x - 7 : x);
-                    x += 2 * (tid & 4);
-                }
-                const int y = jg_partner(x, r, mode);
-                const int lo = x < y ? x : y, hi = x < y ? y : x;
-                const bool live = (lo < 8 ? lo < it.ni : lo - 8 < it.nj) && (hi < 8 ? hi < it.ni : hi - 8 < it.nj);
-                JacRot A = {1.0, 0.0, 0.0, 0.0, 0.0, 0, 0}, B = A;
-                const double aa = Gc[lo * JG_LD + lo].x, bb = Gc[hi * JG_LD + hi].x;
-                const double2 g = Gc[lo * JG_LD + hi];                 // conj(a) . b
-                if (live && aa > z2 && bb > z2) {
-                    const double g2 = fma(g.x, g.x, g.y * g.y);
-                    if (g2 > 0.0 && g2 > tol2 * aa * bb) {
-                        // J = [[c, c q g], [-c q conj(g), c]], q = t / |g|: real diagonal, no phase division.
-                        // cos from cos(2 theta) = |h| / w runs in parallel with the reciprocal that gives q.
-                        const double h = bb - aa, ah = fabs(h);
-                        const double w2 = fma(h, h, 4.0 * g2);
-                        const double iw = fast_rsq(w2);
-                        const double w = w2 * iw;
-                        double q = 2.0 * fast_rcp(ah + w);
-                        q = h >= 0.0 ? q : -q;
-                        const double c2 = fma(0.5 * ah, iw, 0.5);
-                        const double c = c2 * fast_rsq(c2);
-                        const double cq = c * q;
-                        A = {c, 0.0, -cq * g.x, cq * g.y, aa - q * g2, 1, 0};
-                        B = {c, 0.0, cq * g.x, cq * g.y, bb + q * g2, 1, 0};
-                    }
-                }
-                s_rot[lo] = A;
-                s_rot[hi] = B;
-            }
-            __syncthreads();
+            const int ib = jg_partner(ei, r, mode), jb = jg_partner(ej, r, mode);
+            const int ilo = ei < ib ? ei : ib, ihi = ei < ib ? ib : ei;
+            const int jlo = ej < jb ? ej : jb, jhi = ej < jb ? jb : ej;
+            const double iaa = Gc[ilo * JG_LD + ilo].x, ibb = Gc[ihi * JG_LD + ihi].x;
+            const double2 ig = Gc[ilo * JG_LD + ihi];                  // conj(a_lo) . a_hi
+            const double jaa = Gc[jlo * JG_LD + jlo].x, jbb = Gc[jhi * JG_LD + jhi].x;
+            const double2 jg = Gc[jlo * JG_LD + jhi];
+            const double2 gij = Gc[ei * JG_LD + ej], gijb = Gc[ei * JG_LD + jb];
+            const double2 gibj = Gc[ib * JG_LD + ej], gibjb = Gc[ib * JG_LD + jb];
+            const double2 uij = Uc[ei * JG_LD + ej], uijb = Uc[ei * JG_LD + jb];
+            // J = [[c, c q g], [-c q conj(g), c]] on (lo, hi), q = tan / |g|: real diagonal, no phase division;
+            // cos from cos(2 theta) = |h| / w runs in parallel with the reciprocal that gives q
+            double ci = 1.0, cqi = 0.0, dqi = 0.0, cj = 1.0, cqj = 0.0;
+            bool oni = false;
             {
-                const int ib = jg_partner(ei, r, mode), jb = jg_partner(ej, r, mode);
-                const JacRot Ri = s_rot[ei], Rj = s_rot[ej];
-                const double2 jjj = make_double2(Rj.jjr, Rj.jji), jpj = make_double2(Rj.jpr, Rj.jpi);
-                const double2 gij = Gc[ei * JG_LD + ej], gijb = Gc[ei * JG_LD + jb];
-                const double2 gibj = Gc[ib * JG_LD + ej], gibjb = Gc[ib * JG_LD + jb];
-                const double2 uij = Uc[ei * JG_LD + ej], uijb = Uc[ei * JG_LD + jb];
-                double2 t1 = cmul(gij, jjj), t2 = cmul(gijb, jpj);
-                const double2 Tij = make_double2(t1.x + t2.x, t1.y + t2.y);
-                t1 = cmul(gibj, jjj);
-                t2 = cmul(gibjb, jpj);
-                const double2 Tibj = make_double2(t1.x + t2.x, t1.y + t2.y);
-                t1 = cmulc(make_double2(Ri.jjr, Ri.jji), Tij);
-                t2 = cmulc(make_double2(Ri.jpr, Ri.jpi), Tibj);
-                double2 gn = make_double2(t1.x + t2.x, t1.y + t2.y);
-                if (Ri.flag) {
-                    if (ej == ei) gn = make_double2(Ri.dnew, 0.0);
-                    else if (ej == ib) gn = make_double2(0.0, 0.0);
+                const double g2 = fma(ig.x, ig.x, ig.y * ig.y);
+                if (((livemask >> ilo) & (livemask >> ihi) & 1u) && iaa > z2 && ibb > z2 && g2 > 0.0 &&
+                    g2 > tol2 * iaa * ibb) {
+                    const double h = ibb - iaa, ah = fabs(h);
+                    const double w2 = fma(h, h, 4.0 * g2);
+                    const double iw = fast_rsq(w2);
+                    double q = 2.0 * fast_rcp(fma(w2, iw, ah));
+                    q = h >= 0.0 ? q : -q;
+                    const double c2 = fma(0.5 * ah, iw, 0.5);
+                    ci = c2 * fast_rsq(c2);
+                    cqi = ci * q;
+                    dqi = q * g2;
+                    oni = true;
                 }
-                t1 = cmul(uij, jjj);
-                t2 = cmul(uijb, jpj);
-                Gn[ei * JG_LD + ej] = gn;
-                Un[ei * JG_LD + ej] = make_double2(t1.x + t2.x, t1.y + t2.y);
             }
+            {
+                const double g2 = fma(jg.x, jg.x, jg.y * jg.y);
+                if (((livemask >> jlo) & (livemask >> jhi) & 1u) && jaa > z2 && jbb > z2 && g2 > 0.0 &&
+                    g2 > tol2 * jaa * jbb) {
+                    const double h = jbb - jaa, ah = fabs(h);
+                    const double w2 = fma(h, h, 4.0 * g2);
+                    const double iw = fast_rsq(w2);
+                    double q = 2.0 * fast_rcp(fma(w2, iw, ah));
+                    q = h >= 0.0 ? q : -q;
+                    const double c2 = fma(0.5 * ah, iw, 0.5);
+                    cj = c2 * fast_rsq(c2);
+                    cqj = cj * q;
+                }
+            }
+            // column j of J: J[j][j] = c, J[jb][j] = -cq conj(g) if j is the lower index, +cq g if the upper
+            const double2 jpj = ej == jlo ? make_double2(-cqj * jg.x, cqj * jg.y) : make_double2(cqj * jg.x, cqj * jg.y);
+            const double2 ipi = ei == ilo ? make_double2(-cqi * ig.x, cqi * ig.y) : make_double2(cqi * ig.x, cqi * ig.y);
+            double2 t2 = cmul(gijb, jpj);
+            const double2 Tij = make_double2(fma(cj, gij.x, t2.x), fma(cj, gij.y, t2.y));
+            t2 = cmul(gibjb, jpj);
+            const double2 Tibj = make_double2(fma(cj, gibj.x, t2.x), fma(cj, gibj.y, t2.y));
+            t2 = cmulc(ipi, Tibj);
+            double2 gn = make_double2(fma(ci, Tij.x, t2.x), fma(ci, Tij.y, t2.y));
+            if (oni) {      // pivot block by Rutishauser's formulas: a' = a - t|g|, b' = b + t|g|, off-diagonal 0
+                if (ej == ei) gn = make_double2(ei == ilo ? iaa - dqi : ibb + dqi, 0.0);
+                else if (ej == ib) gn = make_double2(0.0, 0.0);
+            }
+            t2 = cmul(uijb, jpj);
+            Gn[ei * JG_LD + ej] = gn;
+            Un[ei * JG_LD + ej] = make_double2(fma(cj, uij.x, t2.x), fma(cj, uij.y, t2.y));
             __syncthreads();
             cur ^= 1;
         }
@@ -890,6 +1205,8 @@ struct JacScratch {
     size_t bytes = 0;
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    hipStream_t aux = nullptr;          // forked stream: small blocks run beside the large-block pipeline
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 static thread_local JacScratch g_js;
 
@@ -903,6 +1220,11 @@ static int js_reserve(size_t dev_bytes, size_t pin_bytes) {
         if (g_js.pinned) HIP_TRY(hipHostFree(g_js.pinned));
         HIP_TRY(hipHostMalloc(&g_js.pinned, pin_bytes * 2));
         g_js.pinned_bytes = pin_bytes * 2;
+    }
+    if (!g_js.aux) {
+        HIP_TRY(hipStreamCreateWithFlags(&g_js.aux, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g_js.ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g_js.ev_join, hipEventDisableTiming));
     }
     return 0;
 }
@@ -921,11 +1243,14 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
                                     lds_elems * (int)sizeof(double2)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_pairs, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     lds_elems * (int)sizeof(double2)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_qr_large, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    16 * (64 * JAC_MAXEL + 1) * (int)sizeof(double2)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_pairs_gram, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (16 * (64 * JAC_MAXEL + 1) + 4 * 16 * JG_LD) * (int)sizeof(double2)));
         attr_set = true;
     }
     // blocks that do not fit one CU's LDS go to the multi-launch block-Jacobi path (needs the host copy of desc)
+    static const int large_min = getenv("HTN_JAC_LARGE_MIN") ? atoi(getenv("HTN_JAC_LARGE_MIN")) : lds_elems;
     std::vector<int> large;
     if (desc_host)
         for (int b = 0; b < n_blocks; ++b) {
@@ -933,12 +1258,11 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
             if (!(D.flags & HTN_SVD_QRCP) || D.n < 2) continue;
             const int gsx = D.m <= 16 * JAC_MAXEL ? 16 : (D.m <= 32 * JAC_MAXEL ? 32 : 64);
             const int mp = gsx * ((D.m + gsx - 1) / gsx);
-            if ((int64_t)mp * D.n > lds_elems) large.push_back(b);
+            if ((int64_t)mp * D.n > large_min) large.push_back(b);
         }
     if (large.empty()) {
         hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2), st, (double2*)G,
-                           (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)nullptr,
-                           (int*)nullptr, (double*)nullptr);
+                           (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)nullptr);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -1027,9 +1351,20 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     HIP_TRY(hipMemcpyAsync(d_ids, h_ids, sizeof(int) * nl, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_slot, h_slot, sizeof(int) * n_blocks, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_done, 0, sizeof(int) * nl, st));
-    // one launch: small blocks run their whole SVD, large blocks their pivoted QR (different CUs, concurrently)
-    hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2), st, (double2*)G,
-                       (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)d_slot, d_perm, d_zero);
+    // large blocks: pivoted QR on this stream, then the sweeps; the small blocks run their whole SVD beside
+    // them on the forked stream and join before the call returns
+    HIP_TRY(hipEventRecord(g_js.ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(g_js.aux, g_js.ev_fork, 0));
+    hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2), g_js.aux,
+                       (double2*)G, (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)d_slot);
+    HIP_TRY(hipEventRecord(g_js.ev_join, g_js.aux));
+    {
+        int max_m0 = 0;
+        for (int li = 0; li < nl; ++li) max_m0 = std::max(max_m0, (int)desc_host[large[li]].pad);
+        const size_t qr_lds = (size_t)16 * (((max_m0 + 15) & ~15) + 1) * sizeof(double2);
+        hipLaunchKernelGGL(k_qr_large, dim3(nl), dim3(JAC_THREADS), qr_lds, st, (double2*)G, (double2*)Vj, desc, d_ids,
+                           d_perm, d_zero);
+    }
     const size_t gram_lds_bytes = (size_t)(16 * (max_mp + 1) + 4 * 16 * JG_LD) * sizeof(double2);
     std::vector<char> last(nl, 0);
     bool all_done = false;
@@ -1063,6 +1398,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     for (int li = 0; li < nl; ++li)
         if (!h_done[li]) h_sw[li] = -h_sw[li];
     HIP_TRY(hipMemcpyAsync(d_sw, h_sw, sizeof(int) * nl, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamWaitEvent(st, g_js.ev_join, 0));
     hipLaunchKernelGGL(k_jacobi_finish, dim3(nl), dim3(JAC_THREADS), 0, st, (double2*)G, (const double2*)Vj, S, desc,
                        d_ids, d_perm, d_sw, info_dev);
     HIP_TRY(hipGetLastError());

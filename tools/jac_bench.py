@@ -43,7 +43,7 @@ def run(m0, n0, flags, reps=5, multi=False):
     return min(ts), int(info.cpu()[0])
 
 
-sizes = [(64, 64), (96, 96), (107, 107), (128, 128), (160, 160), (202, 202), (256, 256), (400, 400)]
+sizes = [(48, 48), (64, 64), (80, 80), (96, 96), (107, 107), (128, 128), (160, 160), (202, 202), (256, 256), (400, 400)]
 if len(sys.argv) > 1:       # e.g. `jac_bench.py 256x256 202x180`: multi-launch path only
     for a in sys.argv[1:]:
         m0, n0 = (int(x) for x in a.split("x"))
