@@ -197,6 +197,45 @@ def test_jacobi_svd_qr_preconditioned(hip_ops, shapes, multi):
         assert np.abs(resid).max() <= 1e-12 * ref[0] ** 2
 
 
+@pytest.mark.parametrize("multi", [False, True])
+def test_jacobi_svd_rank_deficient_large_blocks(hip_ops, multi):
+    """blocks whose numerical rank is below min(m0, n0) -- the two-site block of a bond whose neighbour is not
+    saturated yet -- through the blocked QR (early panel exit) and the Gram-matrix panel visits (zero columns)"""
+    rng = np.random.default_rng(11)
+    shapes = [(200, 200, 120), (150, 180, 33), (260, 140, 1), (120, 120, 120)]
+    desc = np.zeros(len(shapes), dtype=abi.SVD_DT)
+    go = vo = so = 0
+    mats = []
+    for i, (m0, n0, rank) in enumerate(shapes):
+        r = min(m0, n0)
+        desc[i] = (go, vo, so, n0, r, abi.SVD_QRCP, m0)
+        U, _ = np.linalg.qr(_rand_z(rng, m0 * rank).reshape(m0, rank))
+        W, _ = np.linalg.qr(_rand_z(rng, n0 * rank).reshape(n0, rank))
+        s = 10.0 ** (-8 * np.arange(rank) / max(rank - 1, 1))
+        mats.append((U * s) @ W.conj().T)
+        go, vo, so = go + m0 * n0, vo + ((n0 + 63) // 64 * 64) * r, so + r
+    dG = hip_ops.to_device(np.concatenate([M.T.reshape(-1) for M in mats]))
+    dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
+    hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), 260, 40, 1e-14, info,
+                       desc_host=desc if multi else None)
+    Gp, S, inf = hip_ops.to_host(dG), hip_ops.to_host(dS), hip_ops.to_host(info)
+    assert inf.min() >= 0, inf
+    for i, (m0, n0, rank) in enumerate(shapes):
+        d = desc[i]
+        r = min(m0, n0)
+        out = Gp[d["g_off"]:d["g_off"] + n0 * r].reshape(r, n0).T
+        s = S[d["s_off"]:d["s_off"] + r]
+        assert np.isfinite(out).all() and np.isfinite(s).all()
+        ref = np.linalg.svd(mats[i], compute_uv=False)
+        order = np.argsort(-s)
+        assert np.abs(s[order] - ref).max() <= 1e-13 * ref[0]
+        live = s > 1e-11 * ref[0]
+        assert live.sum() == rank
+        Viso = out[:, live] / s[live]
+        assert np.abs(Viso.conj().T @ Viso - np.eye(rank)).max() < 1e-12
+        assert np.abs(np.linalg.norm(mats[i] @ Viso, axis=0) - s[live]).max() <= 1e-12 * ref[0]
+
+
 def test_batched_copy_matches_numpy(hip_ops):
     rng = np.random.default_rng(5)
     src = _rand_z(rng, 5000)
