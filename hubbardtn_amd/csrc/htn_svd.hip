@@ -843,76 +843,25 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
 
 // ---- large blocks: block one-sided Jacobi over several CUs ---------------------------------------------
 // A block whose R^H does not fit one CU's LDS is VALU-bound on that CU (all n/2 pairs of a round on 16
-// waves).  Here the columns are cut into panels of w = 16 (8 for m > 256); one WORKGROUP orthogonalises one
-// PAIR of panels completely inside LDS (one or two inner sweeps), panel pairs of one round run on different
-// CUs, and rounds are separated by kernel boundaries (the only cross-CU synchronisation used: no in-kernel
-// grid barriers).  The host reads one number per block and outer sweep (max squared cosine) to stop.
-#ifndef JAC_INNER
-#define JAC_INNER 1
-#endif
-#ifndef JAC_PANEL_SMALL
-#define JAC_PANEL_SMALL 8
-#endif
-#define JAC_PANEL(mp) ((mp) <= 256 ? JAC_PANEL_SMALL : 8)
+// waves).  Here the columns are cut into panels of w = 8; one WORKGROUP handles one PAIR of panels (a "visit"),
+// the panel pairs of one tournament round run on different CUs, and rounds are separated by kernel boundaries
+// (the only cross-CU synchronisation used: no in-kernel grid barriers).  The host reads one number per block
+// and outer sweep (max squared cosine) to stop.
+#define JAC_PANEL 8
 struct JacPairItem {
     int32_t blk, ci, ni, cj, nj, pad[3];
 };
 
-__global__ __launch_bounds__(JAC_THREADS) void k_jacobi_pairs(double2* __restrict__ Vj,
-                                                              const htn_svd_block* __restrict__ desc,
-                                                              const int* __restrict__ large_ids,
-                                                              const JacPairItem* __restrict__ items,
-                                                              const double* __restrict__ zero2,
-                                                              unsigned long long* __restrict__ ratio_bits,
-                                                              const int* __restrict__ done, double tol) {
-    extern __shared__ double2 g_lds[];
-    __shared__ double s_ratio;
-    const JacPairItem it = items[blockIdx.x];
-    if (done[it.blk]) return;
-    const htn_svd_block D = desc[large_ids[it.blk]];
-    const int m = D.m, tid = threadIdx.x;
-    const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
-    const int E = (m + gsx - 1) / gsx;
-    const int mp = gsx * E;
-    double2* __restrict__ X = Vj + D.v_off;
-    const int nc = it.ni + it.nj;
-    for (int idx = tid; idx < nc * mp; idx += JAC_THREADS) {
-        const int c = idx / mp, i = idx - c * mp;
-        const int col = c < it.ni ? it.ci + c : it.cj + (c - it.ni);
-        g_lds[idx] = X[(int64_t)col * mp + i];
-    }
-    __syncthreads();
-    const DenseCols<double2*> dc = {(double2*)g_lds, mp};
-    const double z2 = zero2[it.blk];
-    double first = 0.0;
-    for (int pass = 0; pass < JAC_INNER; ++pass) {       // at most JAC_INNER inner sweeps per visit
-        if (gsx == 16) jacobi_dispatch_e<16>(dc, E, nc, 1, tol, &s_ratio, tid, z2);
-        else if (gsx == 32) jacobi_dispatch_e<32>(dc, E, nc, 1, tol, &s_ratio, tid, z2);
-        else jacobi_dispatch_e<64>(dc, E, nc, 1, tol, &s_ratio, tid, z2);
-        const double r = s_ratio;
-        __syncthreads();
-        if (pass == 0) first = r;
-        if (r <= 1e-12) break;                   // (squared cosine) quadratic convergence: a second inner sweep
-                                                 // would only confirm; uniform: s_ratio is shared
-    }
-    for (int idx = tid; idx < nc * mp; idx += JAC_THREADS) {
-        const int c = idx / mp, i = idx - c * mp;
-        const int col = c < it.ni ? it.ci + c : it.cj + (c - it.ni);
-        X[(int64_t)col * mp + i] = g_lds[idx];
-    }
-    if (tid == 0 && first > 0.0) atomicMax(&ratio_bits[it.blk], (unsigned long long)__double_as_longlong(first));
-}
-
 // ---- panel-pair visit on the Gram matrix ---------------------------------------------------------------
-// The visit above rotates 2 w = 16 columns of mp rows 15 times in a row: each round is a chain of LDS reads,
-// dots over the column, a lane reduction, the rotation and the write back -- about 1.7 us, almost all of it
-// latency.  The same visit restated so that only ONE pass touches the long columns:
+// Rotating the 2 w = 16 columns of mp rows directly costs, per round, a chain of LDS reads, dots over the
+// columns, a lane reduction, the rotation and the write back -- about 1.7 us, almost all of it latency (the
+// first version of this path did that, 37 us per visit).  Here only ONE pass touches the long columns:
 //   (1) G = P^H P  (16 x 16, Hermitian) on v_mfma_f64_16x16x4_f64, the row range split over the 4 waves;
 //   (2) one cyclic sweep of two-sided Jacobi on G, 8 disjoint rotations per round, accumulating U (16 x 16);
 //       one thread per matrix element, no reductions, two workgroup barriers per round;
 //   (3) P <- P U on the MFMA pipe, written straight back to global.
-// In exact arithmetic this is the visit above (a one-sided rotation of the columns IS the two-sided rotation
-// of their Gram matrix).  In floating point G is re-formed from the columns at every visit, so rounding in
+// In exact arithmetic this is one-sided Jacobi on the columns (a one-sided rotation of two columns IS the
+// two-sided rotation of their Gram matrix).  In floating point G is re-formed from the columns at every visit, so rounding in
 // (2) only perturbs the rotation angles, never the orthogonality test: the stopping criterion is evaluated on
 // the exact Gram of the visit.  The pivot 2 x 2 block is updated with Rutishauser's formulas
 // (a' = a - t|g|, b' = b + t|g|, 0 off-diagonal), which keep the small diagonal entries of a graded Gram
@@ -1229,6 +1178,15 @@ static int js_reserve(size_t dev_bytes, size_t pin_bytes) {
     return 0;
 }
 
+// elements of R^H above which a QRCP block leaves the one-workgroup kernel for the multi-kernel path; the default
+// (0) is "does not fit the LDS window".  Lower values exist to exercise the large-block path on small problems.
+static int g_jac_split = 0;
+extern "C" int32_t htn_jacobi_set_split(int32_t elems) {
+    const int32_t prev = g_jac_split;
+    g_jac_split = elems > 0 ? elems : 0;
+    return prev;
+}
+
 extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc,
                                 const htn_svd_block* desc_host, int32_t n_blocks, int32_t max_m_host,
                                 int32_t max_sweeps, double tol, int32_t* info_dev, void* stream) {
@@ -1241,8 +1199,6 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_svd, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     lds_elems * (int)sizeof(double2)));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_pairs, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    lds_elems * (int)sizeof(double2)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_qr_large, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     16 * (64 * JAC_MAXEL + 1) * (int)sizeof(double2)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_pairs_gram, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1250,7 +1206,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         attr_set = true;
     }
     // blocks that do not fit one CU's LDS go to the multi-launch block-Jacobi path (needs the host copy of desc)
-    static const int large_min = getenv("HTN_JAC_LARGE_MIN") ? atoi(getenv("HTN_JAC_LARGE_MIN")) : lds_elems;
+    const int large_min = g_jac_split > 0 ? std::min(g_jac_split, lds_elems) : lds_elems;
     std::vector<int> large;
     if (desc_host)
         for (int b = 0; b < n_blocks; ++b) {
@@ -1269,8 +1225,6 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
 
     const int nl = (int)large.size();
     // panel-pair work lists, one per round of the round-robin tournament over the column panels of each block
-    static const int use_gram = getenv("HTN_JAC_GRAM") ? atoi(getenv("HTN_JAC_GRAM")) : 1;
-    static const int gram_inner = getenv("HTN_JAC_GRAM_INNER") ? atoi(getenv("HTN_JAC_GRAM_INNER")) : 1;
     std::vector<std::vector<JacPairItem>> rounds;
     std::vector<JacPairItem> intra;
     int max_mp = 0;
@@ -1279,7 +1233,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         const int gsx = D.m <= 16 * JAC_MAXEL ? 16 : (D.m <= 32 * JAC_MAXEL ? 32 : 64);
         const int mp = gsx * ((D.m + gsx - 1) / gsx);
         max_mp = std::max(max_mp, mp);
-        const int w = JAC_PANEL(mp);                       // 2 w columns of mp elements must fit the LDS window
+        const int w = JAC_PANEL;
         const int nb = (D.n + w - 1) / w;
         const int nbp = nb + (nb & 1);
         if ((int)rounds.size() < nbp - 1) rounds.resize(nbp - 1);
@@ -1292,22 +1246,17 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
                 JacPairItem it = {li, a * w, std::min(w, D.n - a * w), c * w, std::min(w, D.n - c * w), {0, 0, 0}};
                 rounds[r].push_back(it);
             }
-        if (nb == 1 && !use_gram) {     // single panel: orthogonalise it against itself
-            if (rounds.empty()) rounds.resize(1);
-            JacPairItem it = {li, 0, D.n, 0, 0, {0, 0, 0}};
-            rounds[0].push_back(it);
+        // the pairs inside each panel, two panels per workgroup, once per outer sweep
+        for (int a = 0; a < nb; a += 2) {
+            const int c = a + 1;
+            JacPairItem it = {li, a * w, std::min(w, D.n - a * w), c < nb ? c * w : 0,
+                              c < nb ? std::min(w, D.n - c * w) : 0, {1, 0, 0}};
+            intra.push_back(it);
         }
-        if (use_gram)          // the pairs inside each panel, two panels per workgroup, once per outer sweep
-            for (int a = 0; a < nb; a += 2) {
-                const int c = a + 1;
-                JacPairItem it = {li, a * w, std::min(w, D.n - a * w), c < nb ? c * w : 0,
-                                  c < nb ? std::min(w, D.n - c * w) : 0, {1, 0, 0}};
-                intra.push_back(it);
-            }
     }
     // the intra-panel visit closes the sweep: one outer sweep fewer than with it in front (measured on graded
     // spectra and in the DMRG sweep; the cross visits leave the panels' own pairs slightly non-orthogonal)
-    if (use_gram) rounds.push_back(intra);
+    rounds.push_back(intra);
     size_t n_items = 0;
     for (auto& r : rounds) n_items += r.size();
     // device scratch layout: [large_ids | slot of every block | perm | zero2 | ratio | done | sweeps | items]
@@ -1374,14 +1323,8 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         HIP_TRY(hipMemsetAsync(d_ratio, 0, 8 * nl, st));
         for (size_t r = 0; r < rounds.size(); ++r)
             if (!rounds[r].empty()) {
-                if (use_gram)
-                    hipLaunchKernelGGL(k_jacobi_pairs_gram, dim3((unsigned)rounds[r].size()), dim3(256),
-                                       gram_lds_bytes, st, (double2*)Vj, desc, d_ids, d_items + r_off[r], d_zero,
-                                       d_ratio, d_done, tol, gram_inner);
-                else
-                    hipLaunchKernelGGL(k_jacobi_pairs, dim3((unsigned)rounds[r].size()), dim3(JAC_THREADS),
-                                       lds_elems * sizeof(double2), st, (double2*)Vj, desc, d_ids,
-                                       d_items + r_off[r], d_zero, d_ratio, d_done, tol);
+                hipLaunchKernelGGL(k_jacobi_pairs_gram, dim3((unsigned)rounds[r].size()), dim3(256), gram_lds_bytes, st,
+                                   (double2*)Vj, desc, d_ids, d_items + r_off[r], d_zero, d_ratio, d_done, tol, 1);
             }
         HIP_TRY(hipMemcpyAsync(h_ratio, d_ratio, 8 * nl, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

@@ -146,6 +146,10 @@ class HipOps:
                                                       nblocks, max_m, max_sweeps, float(tol), self._p(info),
                                                       self._stream()), "htn_jacobi_svd_z")
 
+    def jacobi_set_split(self, elems: int) -> int:
+        """threshold (elements of R^H) above which a block takes the large-block SVD path; returns the previous one"""
+        return int(self.lib.htn_jacobi_set_split(int(elems)))
+
     def batched_copy(self, dst, src, idx, scl, items_dev, nitems, gscale):
         if nitems == 0:
             return

@@ -145,6 +145,13 @@ int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc, co
                      int32_t n_blocks, int32_t max_m_host, int32_t max_sweeps, double tol, int32_t* info_dev,
                      void* stream);
 
+/* Blocks whose R^H (roundup(m) x n elements) exceeds `elems` leave the one-workgroup kernel for the large-block
+ * path (k_qr_large: panel-blocked pivoted QR; k_jacobi_pairs_gram: block Jacobi over many CUs).  elems <= 0 restores
+ * the default ("does not fit one CU's LDS window", 9216 elements); values above the default are clamped to it.
+ * Returns the previous setting.  Exists so that small problems can exercise the large-block path (tests); results
+ * agree to the Jacobi tolerance either way.  Process-wide, not thread safe. */
+int32_t htn_jacobi_set_split(int32_t elems);
+
 /* dst(r x c, ldd) = op(src)(.., lds) with optional per-row / per-column real scaling:
  * generic batched strided copy used to (a) stage M or M^H into the Jacobi workspace and
  * (b) write the truncated isometries U[:, keep] / V^H[keep, :] and the centre S*V^H / U*S.

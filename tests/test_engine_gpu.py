@@ -56,6 +56,31 @@ def test_truncated_sweeps_match_oracle(hip_ops, L, t, u, chi):
             assert np.abs(a - b).max() <= 1e-8 * a.max()
 
 
+def test_large_block_svd_path_matches_oracle(hip_ops):
+    """the same truncated sweeps with every block of more than 16 elements forced through the large-block SVD
+    path (k_qr_large + k_jacobi_pairs_gram + k_jacobi_finish), which at these sizes is otherwise only reached
+    at chi >= ~512: energies and spectra must still match the oracle to the north_star tolerance, and the result
+    must equal the default path's to the Jacobi tolerance"""
+    L, t, u, chi = 8, [1.0], [4.0], 64
+    ref = _oracle_run(L, t, u, chi, 2, 6)
+    base, _ = _hip_run(hip_ops, L, t, u, chi, 2, 6)
+    prev = hip_ops.jacobi_set_split(16)
+    try:
+        out, eng = _hip_run(hip_ops, L, t, u, chi, 2, 6)
+    finally:
+        hip_ops.jacobi_set_split(prev)
+    for (Er, sr), (Eg, sg), (Eb, sb) in zip(ref, out, base):
+        assert abs(Eg - Er) <= 1e-8 * abs(Er)
+        assert abs(Eg - Eb) <= 1e-11 * abs(Eb)
+    sr, sg = ref[-1][1], out[-1][1]
+    for bond in sr:
+        assert set(sr[bond]) == set(sg[bond])
+        for c in sr[bond]:
+            a, b = np.asarray(sr[bond][c]), np.asarray(sg[bond][c])
+            assert a.shape == b.shape
+            assert np.abs(a - b).max() <= 1e-8 * a.max()
+
+
 def _generic_oracle_vs_hip(ops, mpo_sites, nsites, target, chi, nsweeps, cap, seed=11):
     """run oracle and HIP engine on the SAME reduced MPO object (any model) from the same start"""
     bonds, tens = mps.random_mps(nsites, target, cap, seed)
