@@ -189,7 +189,7 @@ class DMRG2:
         ops = self.ops
 
         def build():
-            tz, ty, zsize, nterms = pl.plan_apply(tl, self.Llay[i], self.Rlay[i + 2], self.mpo[i], self.mpo[i + 1])
+            tz, ty, zsize, nterms = pl.plan_apply_cached(tl, self.Llay[i], self.Rlay[i + 2], self.mpo[i], self.mpo[i + 1])
             flops = ty.flops + (tz.flops if tz is not None else 0)
             ntiles = ty.ntiles + (tz.ntiles if tz else 0)
             nsegs = ty.nsegs + (tz.nsegs if tz else 0)

@@ -299,41 +299,46 @@ class TaskList:
         segs = np.array(seg_rows, dtype=SEG_DT) if seg_rows else np.zeros(1, dtype=SEG_DT)
         if not blk_rows:
             return Tasks(np.zeros(1, dtype=TILE_DT), 0, segs, pos, flops)
-        B = np.array(blk_rows, dtype=np.int64)
-        if seg_rows:
-            # pre-split every GEMM segment into 16-deep K slabs (tile.pad1 = 1): the kernel's quads then walk the
-            # slab list without reading segment records, and fetch each slab's descriptor one round ahead
-            gem = segs["type"] == SEG_GEMM
-            nch = np.where(gem, (segs["k"] + 15) // 16, 1).astype(np.int64)
-            cum = np.concatenate([[0], np.cumsum(nch)])
-            rep = np.repeat(segs, nch)
-            k0 = (np.arange(len(rep)) - np.repeat(cum[:-1], nch)) * 16
-            g = rep["type"] == SEG_GEMM
-            rep["a_off"] += np.where(g, np.where(rep["op_a"] == OP_N, k0 * rep["lda"], k0), 0)
-            rep["b_off"] += np.where(g, np.where(rep["op_b"] == OP_N, k0, k0 * rep["ldb"]), 0)
-            rep["k"] = np.where(g, np.minimum(16, rep["k"] - k0), rep["k"])
-            B[:, 6] = cum[B[:, 5] + B[:, 6]] - cum[B[:, 5]]
-            B[:, 5] = cum[B[:, 5]]
-            segs = np.ascontiguousarray(rep)
-            pos = len(segs)
-        ntr = (B[:, 3] + HTN_TILE - 1) // HTN_TILE
-        ntc = (B[:, 4] + HTN_TILE - 1) // HTN_TILE
-        nt = ntr * ntc
-        bi = np.repeat(np.arange(len(B)), nt)                         # block index of every tile
-        first = np.repeat(np.cumsum(nt) - nt, nt)
-        loc = np.arange(int(nt.sum())) - first                        # tile index inside its block
-        r0 = (loc // ntc[bi]) * HTN_TILE
-        c0 = (loc % ntc[bi]) * HTN_TILE
-        tarr = np.zeros(len(bi), dtype=TILE_DT)
-        tarr["c_off"], tarr["buf_c"], tarr["ldc"] = B[bi, 0], B[bi, 1], B[bi, 2]
-        tm = np.minimum(HTN_TILE, B[bi, 3] - r0)
-        tn = np.minimum(HTN_TILE, B[bi, 4] - c0)
-        tarr["m"], tarr["n"], tarr["row0"], tarr["col0"] = tm, tn, r0, c0
-        tarr["seg_begin"], tarr["seg_count"], tarr["pad0"] = B[bi, 5], B[bi, 6], B[bi, 7]
-        tarr["pad1"] = 1
-        work = tm * tn * (B[bi, 8] + 1)
-        tarr = tarr[np.argsort(-work, kind="stable")]                 # longest first: dispatch order = LPT schedule
-        return Tasks(np.ascontiguousarray(tarr), len(tarr), segs, pos, flops)
+        return _emit_tasks(segs, bool(seg_rows), np.array(blk_rows, dtype=np.int64), pos, flops)
+
+
+def _emit_tasks(segs, have_segs, B, pos, flops):
+    """segment records + block table (off, buf, ld, m, n, seg_begin, seg_count, ncopy, ksum) -> Tasks:
+    K pre-split of the GEMM segments and ALL tiles in one vectorised pass"""
+    if have_segs:
+        # pre-split every GEMM segment into 16-deep K slabs (tile.pad1 = 1): the kernel's quads then walk the
+        # slab list without reading segment records, and fetch each slab's descriptor one round ahead
+        gem = segs["type"] == SEG_GEMM
+        nch = np.where(gem, (segs["k"] + 15) // 16, 1).astype(np.int64)
+        cum = np.concatenate([[0], np.cumsum(nch)])
+        rep = np.repeat(segs, nch)
+        k0 = (np.arange(len(rep)) - np.repeat(cum[:-1], nch)) * 16
+        g = rep["type"] == SEG_GEMM
+        rep["a_off"] += np.where(g, np.where(rep["op_a"] == OP_N, k0 * rep["lda"], k0), 0)
+        rep["b_off"] += np.where(g, np.where(rep["op_b"] == OP_N, k0, k0 * rep["ldb"]), 0)
+        rep["k"] = np.where(g, np.minimum(16, rep["k"] - k0), rep["k"])
+        B[:, 6] = cum[B[:, 5] + B[:, 6]] - cum[B[:, 5]]
+        B[:, 5] = cum[B[:, 5]]
+        segs = np.ascontiguousarray(rep)
+        pos = len(segs)
+    ntr = (B[:, 3] + HTN_TILE - 1) // HTN_TILE
+    ntc = (B[:, 4] + HTN_TILE - 1) // HTN_TILE
+    nt = ntr * ntc
+    bi = np.repeat(np.arange(len(B)), nt)                         # block index of every tile
+    first = np.repeat(np.cumsum(nt) - nt, nt)
+    loc = np.arange(int(nt.sum())) - first                        # tile index inside its block
+    r0 = (loc // ntc[bi]) * HTN_TILE
+    c0 = (loc % ntc[bi]) * HTN_TILE
+    tarr = np.zeros(len(bi), dtype=TILE_DT)
+    tarr["c_off"], tarr["buf_c"], tarr["ldc"] = B[bi, 0], B[bi, 1], B[bi, 2]
+    tm = np.minimum(HTN_TILE, B[bi, 3] - r0)
+    tn = np.minimum(HTN_TILE, B[bi, 4] - c0)
+    tarr["m"], tarr["n"], tarr["row0"], tarr["col0"] = tm, tn, r0, c0
+    tarr["seg_begin"], tarr["seg_count"], tarr["pad0"] = B[bi, 5], B[bi, 6], B[bi, 7]
+    tarr["pad1"] = 1
+    work = tm * tn * (B[bi, 8] + 1)
+    tarr = tarr[np.argsort(-work, kind="stable")]                 # longest first: dispatch order = LPT schedule
+    return Tasks(np.ascontiguousarray(tarr), len(tarr), segs, pos, flops)
 
 
 @dataclass
@@ -421,6 +426,204 @@ def plan_apply(tl: ThetaLayout, Ll: EnvLayout, Rl: EnvLayout, W1, W2):
                                         tz.gemm(zk, BUF_L, lo, lm, OP_N, BUF_X, xoff, xld, OP_N, ln, alpha)
     tasks_z = tz.finalize() if zblocks else None
     return tasks_z, ty.finalize(), zoff, nterms
+
+
+# ---- dimension-independent ("symbolic") apply plans -------------------------------------------------
+# Which blocks meet in which segment, and with which recoupling coefficient, depends only on WHICH sectors
+# the two outer bonds hold -- not on their multiplicities.  Near convergence the multiplicities still move
+# by a few states from sweep to sweep (every change is a miss of the numeric plan cache, 7-25 ms of Python
+# loops here), the sector sets almost never do.  ApplySym keeps the loop-generated structure as index arrays
+# into the layouts' block tables; instantiate() turns it into the numeric task lists with a handful of
+# numpy gathers (~1 ms).  tests/test_host_cpu.py checks instantiate() == plan_apply() byte for byte.
+def _wkey(W):
+    k = getattr(W, "_ckey", None)
+    if k is None:
+        k = (tuple(W.left), tuple(W.right), tuple(W.entries))
+        W._ckey = k
+    return k
+
+
+_KIND_C, _KIND_L, _KIND_R, _KIND_Z = 0, 1, 2, 3
+
+
+class ApplySym:
+    __slots__ = ("nterms", "y", "z", "z_first")
+
+    @staticmethod
+    def _flatten(per_block, nblocks):
+        """per_block: list of {symkey: alpha} in block order -> arrays (blk, kind, i1, i2, alpha) + per-block
+        (seg_begin, seg_count, ncopy), GEMM segments first (stable), zero coefficients dropped"""
+        blk, kind, i1, i2, al = [], [], [], [], []
+        begin = np.zeros(nblocks, dtype=np.int64)
+        count = np.zeros(nblocks, dtype=np.int64)
+        ncopy = np.zeros(nblocks, dtype=np.int64)
+        pos = 0
+        for b, d in enumerate(per_block):
+            items = [(k, a) for k, a in d.items() if a != 0.0]
+            items.sort(key=lambda t: t[0][0] == _KIND_C)         # GEMM segments first, COPY segments last
+            begin[b] = pos
+            count[b] = len(items)
+            for (kd, a1, a2), a in items:
+                blk.append(b)
+                kind.append(kd)
+                i1.append(a1)
+                i2.append(a2)
+                al.append(a)
+                ncopy[b] += kd == _KIND_C
+            pos += len(items)
+        return (np.array(blk, dtype=np.int64), np.array(kind, dtype=np.int64), np.array(i1, dtype=np.int64),
+                np.array(i2, dtype=np.int64), np.array(al, dtype=np.complex128), begin, count, ncopy)
+
+    @staticmethod
+    def build(tl, Ll, Rl, W1, W2):
+        """the loop nest of plan_apply, recording block INDICES instead of offsets and sizes"""
+        nfin = len(W2.right) - 1
+        w2 = _w_by_left(W2)
+        tidx = {k: i for i, k in enumerate(tl.blocks)}
+        lidx = {k: i for i, k in enumerate(Ll.blocks)}
+        ridx = {k: i for i, k in enumerate(Rl.blocks)}
+        ysegs = [dict() for _ in tidx]
+        zsegs, zfirst, zidx = [], [], {}
+        nterms = 0
+        for beta, xi in tidx.items():
+            a, s1, c, s2, b = beta
+            js1, js2 = SITE_MULT[s1][1], SITE_MULT[s2][1]
+            for (w, wm, n1, c1) in W1.entries:
+                k1, dN1, red1 = SITE_OPS[n1]
+                kw, kmid = W1.left[w][1], W1.right[wm][1]
+                aps = [a] if w == 0 else Ll.by_ket.get((w, a), [])
+                if not aps:
+                    continue
+                for s1p in range(3):
+                    r1 = red1[s1p, s1]
+                    if r1 == 0.0:
+                        continue
+                    for (_, wp, n2, c2) in w2.get(wm, []):
+                        k2, dN2, red2 = SITE_OPS[n2]
+                        kwp = W2.right[wp][1]
+                        bps = [b] if wp == nfin else Rl.by_ket.get((wp, b), [])
+                        if not bps:
+                            continue
+                        for s2p in range(3):
+                            r2 = red2[s2p, s2]
+                            if r2 == 0.0:
+                                continue
+                            for ap in aps:
+                                for cp in fuse(ap, s1p):
+                                    for bp in bps:
+                                        oi = tidx.get((ap, s1p, cp, s2p, bp))
+                                        if oi is None:
+                                            continue
+                                        cf = coef_apply(a[1], ap[1], kw, js1, SITE_MULT[s1p][1], k1, kmid, c[1],
+                                                        cp[1], js2, SITE_MULT[s2p][1], k2, kwp, b[1], bp[1])
+                                        alpha = cf * r1 * r2 * c1 * c2
+                                        if alpha == 0.0:
+                                            continue
+                                        nterms += 1
+                                        hasL, hasR = (w != 0), (wp != nfin)
+                                        d = ysegs[oi]
+                                        if not hasL and not hasR:
+                                            key = (_KIND_C, xi, 0)
+                                            d[key] = d.get(key, 0.0) + alpha
+                                        elif hasL and not hasR:
+                                            key = (_KIND_L, lidx[(ap, w, a)], xi)
+                                            d[key] = d.get(key, 0.0) + alpha
+                                        elif hasR and not hasL:
+                                            key = (_KIND_R, xi, ridx[(b, wp, bp)])
+                                            d[key] = d.get(key, 0.0) + alpha
+                                        else:
+                                            li, ri = lidx[(ap, w, a)], ridx[(b, wp, bp)]
+                                            zk = (oi, wp, b)
+                                            zi = zidx.get(zk)
+                                            if zi is None:
+                                                zi = zidx[zk] = len(zsegs)
+                                                zsegs.append({})
+                                                zfirst.append((li, xi))
+                                                key = (_KIND_Z, zi, ri)
+                                                d[key] = d.get(key, 0.0) + 1.0
+                                            dz = zsegs[zi]
+                                            key = (_KIND_L, li, xi)
+                                            dz[key] = dz.get(key, 0.0) + alpha
+        sym = ApplySym()
+        sym.nterms = nterms
+        sym.y = ApplySym._flatten(ysegs, len(tidx))
+        sym.z = ApplySym._flatten(zsegs, len(zsegs)) if zsegs else None
+        sym.z_first = np.array(zfirst, dtype=np.int64).reshape(-1, 2)
+        return sym
+
+    @staticmethod
+    def _segs(flat, X, Lb, Rb, zoff, zm):
+        blk, kind, i1, i2, al, begin, count, ncopy = flat
+        n = len(blk)
+        segs = np.zeros(max(n, 1), dtype=SEG_DT)
+        if n == 0:
+            return segs, np.zeros(len(begin), dtype=np.int64)
+        isC, isL, isR, isZ = kind == _KIND_C, kind == _KIND_L, kind == _KIND_R, kind == _KIND_Z
+        # operand A
+        iL = np.where(isL, i1, 0)
+        iXa = np.where(isR, i1, 0)
+        iZ = np.where(isZ, i1, 0)
+        a_off = np.where(isL, Lb[iL, 0], np.where(isR, X[iXa, 0], np.where(isZ, zoff[iZ], 0)))
+        lda = np.where(isL, Lb[iL, 1], np.where(isR, X[iXa, 3], np.where(isZ, zm[iZ], 1)))
+        buf_a = np.where(isL, BUF_L, np.where(isR, BUF_X, np.where(isZ, BUF_Z, 0)))
+        # operand B
+        iXb = np.where(isC, i1, np.where(isL, i2, 0))
+        iR = np.where(isR | isZ, i2, 0)
+        useX = isC | isL
+        b_off = np.where(useX, X[iXb, 0], Rb[iR, 0])
+        ldb = np.where(useX, X[iXb, 3], Rb[iR, 1])
+        buf_b = np.where(useX, BUF_X, BUF_R)
+        k = np.where(isL, Lb[iL, 2], np.where(isR | isZ, Rb[iR, 1], 0))
+        segs["a_off"], segs["b_off"], segs["buf_a"], segs["buf_b"] = a_off, b_off, buf_a, buf_b
+        segs["lda"], segs["ldb"], segs["k"] = lda, ldb, k
+        segs["op_a"], segs["op_b"] = OP_N, OP_N
+        segs["type"] = np.where(isC, SEG_COPY, SEG_GEMM)
+        segs["alpha_re"], segs["alpha_im"] = al.real, al.imag
+        ksum = np.bincount(blk, weights=np.where(isC, 0, k), minlength=len(begin)).astype(np.int64)
+        return segs, ksum
+
+    def instantiate(self, tl, Ll, Rl):
+        """-> (stageZ Tasks | None, stageY Tasks, z_size, nterms), identical to plan_apply(tl, Ll, Rl, W1, W2)"""
+        X = np.array(list(tl.blocks.values()), dtype=np.int64).reshape(-1, 4)
+        # (an environment at a chain end holds no blocks: one dummy row keeps the gathers below in range)
+        Lb = np.array(list(Ll.blocks.values()) or [(0, 1, 0)], dtype=np.int64).reshape(-1, 3)
+        Rb = np.array(list(Rl.blocks.values()) or [(0, 1, 0)], dtype=np.int64).reshape(-1, 3)
+        if self.z is not None:
+            zm = Lb[self.z_first[:, 0], 1]
+            zn = X[self.z_first[:, 1], 2]
+            zsz = zm * zn
+            zoff = np.cumsum(zsz) - zsz
+            zsize = int(zsz.sum())
+        else:
+            zm = zn = zoff = np.zeros(1, dtype=np.int64)
+            zsize = 0
+        none = np.zeros(1, dtype=np.int64)
+        segs, ksum = ApplySym._segs(self.y, X, Lb, Rb, zoff, zm)
+        nb = len(X)
+        B = np.stack([X[:, 0], np.full(nb, BUF_Y), X[:, 3], X[:, 1], X[:, 2], self.y[5], self.y[6], self.y[7], ksum], axis=1)
+        ny = len(self.y[0])
+        ty = _emit_tasks(segs, ny > 0, B.astype(np.int64), ny, int(8 * (X[:, 1] * X[:, 2] * ksum).sum()))
+        tz = None
+        if self.z is not None:
+            segz, ksz = ApplySym._segs(self.z, X, Lb, Rb, none, none)
+            Bz = np.stack([zoff, np.full(len(zm), BUF_Z), zm, zm, zn, self.z[5], self.z[6], self.z[7], ksz], axis=1)
+            nz = len(self.z[0])
+            tz = _emit_tasks(segz, nz > 0, Bz.astype(np.int64), nz, int(8 * (zm * zn * ksz).sum()))
+        return tz, ty, zsize, self.nterms
+
+
+_APPLY_SYM = {}
+
+
+def plan_apply_cached(tl: ThetaLayout, Ll: EnvLayout, Rl: EnvLayout, W1, W2):
+    """plan_apply through the symbolic cache (keyed by the sector SETS of the outer bonds and the MPO sites)"""
+    key = (tuple(tl.bond_l.secs), tuple(tl.bond_r.secs), _wkey(W1), _wkey(W2))
+    sym = _APPLY_SYM.get(key)
+    if sym is None:
+        if len(_APPLY_SYM) > 4000:
+            _APPLY_SYM.clear()
+        sym = _APPLY_SYM[key] = ApplySym.build(tl, Ll, Rl, W1, W2)
+    return sym.instantiate(tl, Ll, Rl)
 
 
 def plan_theta(mode, lay1: SiteLayout, lay2: SiteLayout, tl: ThetaLayout):

@@ -224,3 +224,46 @@ def test_polyacetylene_parameters_build_and_sweep_on_emulator():
     assert Es[-1] >= w[0] - 1e-9              # variational
     # the N=4 singlet ground state is one of the eigenvalues of the full matrix
     assert np.abs(w - Es[-1]).min() < 1e-8
+
+
+def test_symbolic_apply_plan_equals_loop_plan():
+    """the dimension-independent plan instantiated on perturbed multiplicities is byte-identical to the plan the
+    loop nest builds from scratch (one-band NN, NNN and the two-band model)"""
+    from hubbardtn_amd import models, planner as pl
+    rng = np.random.default_rng(3)
+    tab = {(2, 0): 2, (2, 2): 1, (3, 1): 5, (3, 3): 3, (4, 0): 7, (4, 2): 9, (4, 4): 2, (5, 1): 11, (5, 3): 6,
+           (6, 0): 8, (6, 2): 9, (6, 4): 3, (7, 1): 5, (7, 3): 2, (8, 0): 2}
+
+    def same(a, b):
+        if a is None or b is None:
+            return a is b
+        return (a.ntiles == b.ntiles and a.nsegs == b.nsegs and a.flops == b.flops
+                and a.tiles.tobytes() == b.tiles.tobytes() and a.segs.tobytes() == b.segs.tobytes())
+    tm = np.array([[0.0, 1.0, 0.1, 0.0], [1.0, 0.0, 0.8, 0.05]])
+    um = np.array([[4.0, 1.0, 0.0, 0.0], [1.0, 4.0, 0.5, 0.0]])
+    mpos = [models.hamiltonian(models.OB_Sim([1.0], [4.0]), 12), models.hamiltonian(models.OB_Sim([1.0, 0.1], [4.0, 0.5]), 12),
+            models.hamiltonian(models.MB_Sim(tm, um, np.zeros_like(um), 1, 1, 2.0, 8), 6)]
+    for mpo in mpos:
+        for trial in range(3):
+            pert = lambda n: max(1, int(n + rng.integers(-2, 3)))
+            bl = pl.Bond({(N + 2, j): pert(n) for (N, j), n in tab.items()})
+            br = pl.Bond({(N + 4, j): pert(n) for (N, j), n in tab.items()})
+            tl = pl.ThetaLayout.build(bl, br)
+            Ll = pl.EnvLayout.build("L", bl, mpo[5].left)
+            Rl = pl.EnvLayout.build("R", br, mpo[6].right)
+            ref = pl.plan_apply(tl, Ll, Rl, mpo[5], mpo[6])
+            new = pl.plan_apply_cached(tl, Ll, Rl, mpo[5], mpo[6])
+            assert same(ref[0], new[0]) and same(ref[1], new[1]) and ref[2:] == new[2:]
+    # every bond of a short chain, chain ends (empty environments, tiny sector tables) included
+    from hubbardtn_amd import mps
+    L = 8
+    mpo = models.hamiltonian(models.OB_Sim([1.0, 0.3], [4.0]), L)
+    bonds, _ = mps.random_mps(L, (L, 0), 5, seed=2)
+    bonds = [pl.Bond(b) for b in bonds]
+    for i in range(L - 1):
+        tl = pl.ThetaLayout.build(bonds[i], bonds[i + 2])
+        Ll = pl.EnvLayout.build("L", bonds[i], mpo[i].left)
+        Rl = pl.EnvLayout.build("R", bonds[i + 2], mpo[i + 1].right)
+        ref = pl.plan_apply(tl, Ll, Rl, mpo[i], mpo[i + 1])
+        new = pl.plan_apply_cached(tl, Ll, Rl, mpo[i], mpo[i + 1])
+        assert same(ref[0], new[0]) and same(ref[1], new[1]) and ref[2:] == new[2:], i
