@@ -12,10 +12,11 @@ and the plugin boundary MPSKit exposes to it,
 
 with `alg = DMRG2(trscheme=truncdim(D) | truncbelow(eta), tol, maxiter, verbosity)`.
 
-Differences forced by scope: the reference only runs INFINITE chains (IDMRG2); this
-engine runs the finite-chain two-site sweep that BASELINE.json's L=... configs name, so a chain
-length must be given (`L=` keyword / `simul.kwargs["L"]`).  All compute goes through the HIP
-library; there is no CPU path.
+Two drivers share the hot path: with a chain length (`L=` keyword / `simul.kwargs["L"]`) the
+finite two-site sweep DMRG2 that BASELINE.json's L=... configs name; without one the infinite-chain IDMRG2 the
+reference itself calls (src:1010), here in McCulloch's growing-window form (hubbardtn_amd/idmrg.py) with the
+reference's truncation default truncbelow(10^-svalue).  All compute goes through the HIP library; there is no CPU
+path.
 """
 from __future__ import annotations
 
@@ -24,6 +25,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import engine as _engine
+from . import idmrg as _idmrg
 from . import models, mps
 from .models import MB_Sim, OB_Sim, Simulation
 
@@ -53,6 +55,42 @@ class DMRG2:
 
 
 @dataclass
+class IDMRG2:
+    """infinite two-site DMRG selector (MPSKit.IDMRG2 keyword names; the call at src:1010)"""
+    trscheme: object = None
+    tol: float = 1e-6              # on the change of the centre Schmidt spectrum (MPSKit: ||C_old - C_new||)
+    maxiter: int = 100
+    verbosity: int = 0
+    krylovdim: int = 30
+    eigsolve_tol: float = 1e-10
+    sweeps_per_step: int = 4       # finite sweeps of the 2-cell window per growth step
+
+
+@dataclass
+class InfiniteHamiltonian:
+    """the model of a translation-invariant chain; len() = sites per unit cell (length(H) in the reference)"""
+    simul: Simulation
+
+    def __len__(self):
+        return _idmrg.unit_cell(self.simul.P, self.simul.Q) * self.simul.bands
+
+
+@dataclass
+class InfiniteMPS:
+    """handle of an infinite MPS: before optimisation only the start parameters, afterwards the IDMRGResult"""
+    max_dimension: int
+    seed: int = 1234
+    ops: object = None
+    result: object = None
+
+    def bond_dimensions(self):
+        if self.result is None:
+            raise RuntimeError("run find_groundstate first")
+        T = self.result.unit_cell
+        return list(self.result.bond_dims[T // 2 + 1:T // 2 + 1 + T])     # the central unit cell of the last window
+
+
+@dataclass
 class FiniteMPS:
     """device-resident finite MPS handle (wraps the sweep engine's state)"""
     engine: object
@@ -79,9 +117,10 @@ def _ops(device=0):
 
 
 def hamiltonian(simul: Simulation, L: int | None = None):
+    """finite open chain of L unit cells -> list of MPO sites; no L -> the infinite chain (src:386-472, 811-910)"""
     L = L or simul.kwargs.get("L")
     if L is None:
-        raise ValueError("finite-chain engine: pass L (number of unit cells)")
+        return InfiniteHamiltonian(simul)
     return models.hamiltonian(simul, int(L))
 
 
@@ -89,6 +128,8 @@ def initialize_mps(H, P: int, max_dimension: int, spin: bool = False, Q: int = 1
     """random right-canonical start with per-sector cap `max_dimension` (src:917-959)"""
     if spin:
         raise NotImplementedError("U(1)xU(1) spinful mode is a 'next' row (SURVEY 8f.2)")
+    if isinstance(H, InfiniteHamiltonian):
+        return InfiniteMPS(int(max_dimension), seed, ops)
     nsites = len(H)
     if (nsites * P) % Q:
         raise ValueError("filling P/Q incompatible with the chain length")
@@ -100,7 +141,23 @@ def initialize_mps(H, P: int, max_dimension: int, spin: bool = False, Q: int = 1
 
 def find_groundstate(psi: FiniteMPS, H, alg: DMRG2, envs=None):
     """-> (psi, envs, delta); delta = |E_sweep - E_previous sweep| / L at exit (MPSKit returns the
-    last convergence error).  Sweeps until delta < alg.tol or maxiter."""
+    last convergence error).  Sweeps until delta < alg.tol or maxiter.  With an InfiniteMPS / IDMRG2: growth steps
+    until the centre Schmidt spectrum changes by less than alg.tol."""
+    if isinstance(psi, InfiniteMPS):
+        if not isinstance(alg, IDMRG2) or not isinstance(H, InfiniteHamiltonian):
+            raise TypeError("an InfiniteMPS is optimised with IDMRG2 on hamiltonian(simul) without a chain length")
+        chi, cut = None, 0.0
+        if isinstance(alg.trscheme, truncdim):
+            chi = int(alg.trscheme.D)
+        elif isinstance(alg.trscheme, truncbelow):
+            cut = float(alg.trscheme.eta)
+        elif alg.trscheme is not None:
+            raise TypeError("trscheme must be truncdim(D) or truncbelow(eta)")
+        psi.result = _idmrg.idmrg2(psi.ops or _ops(), H.simul, chi_full=chi, cutoff=cut, tol=alg.tol,
+                                   maxiter=alg.maxiter, sweeps_per_step=alg.sweeps_per_step,
+                                   init_dimension=psi.max_dimension, krylovdim=alg.krylovdim,
+                                   lanczos_tol=alg.eigsolve_tol, seed=psi.seed, verbosity=alg.verbosity)
+        return psi, Environments(psi.result.engine), psi.result.delta
     eng = psi.engine
     if isinstance(alg.trscheme, truncdim):
         eng.chi_full, eng.cutoff = int(alg.trscheme.D), 0.0
@@ -131,7 +188,11 @@ def compute_groundstate(simul: Simulation, L: int | None = None, tol: float = 1e
     spin = bool(simul.kwargs.get("spin", False))
     psi0 = init_state if init_state is not None else initialize_mps(H, simul.P, simul.bond_dim, spin, simul.Q)
     scheme = truncdim(chi) if chi is not None else truncbelow(10.0 ** (-simul.svalue))
-    psi, envs, delta = find_groundstate(psi0, H, DMRG2(trscheme=scheme, tol=tol, verbosity=verbosity, maxiter=maxiter))
+    if isinstance(H, InfiniteHamiltonian):       # src:1010; the VUMPS / GradientGrassmann polish (src:1025-1027) is out of scope
+        alg = IDMRG2(trscheme=scheme, tol=tol, verbosity=verbosity, maxiter=maxiter)
+    else:
+        alg = DMRG2(trscheme=scheme, tol=tol, verbosity=verbosity, maxiter=maxiter)
+    psi, envs, delta = find_groundstate(psi0, H, alg)
     return {"groundstate": psi, "environments": envs, "ham": H, "delta": delta, "config": simul}
 
 
@@ -143,6 +204,10 @@ def produce_groundstate(simul: Simulation, force: bool = False, **kw):
 def expectation_value(psi: FiniteMPS, H):
     """energy per site as a length-L vector whose sum / L is E/L (examples/One_band.jl:42-43 take
     sum(real(E0)) / length(H)); the finite engine knows the total energy from its last eigensolve."""
+    if isinstance(psi, InfiniteMPS):
+        if psi.result is None:
+            raise RuntimeError("run find_groundstate first")
+        return np.full(len(H), psi.result.energy_per_site)
     E = psi.engine.energy
     if E is None:
         raise RuntimeError("run find_groundstate first")
@@ -151,4 +216,6 @@ def expectation_value(psi: FiniteMPS, H):
 
 def dim_state(psi: FiniteMPS):
     """bond dimensions in TensorKit `dim` units (src:1399-1405)"""
+    if isinstance(psi, InfiniteMPS):
+        return psi.bond_dimensions()
     return psi.engine.bond_dims()[1:]

@@ -58,7 +58,8 @@ class DMRG2:
     """
 
     def __init__(self, ops, mpo, bonds, tensors, chi_full=None, cutoff=0.0, krylovdim=30, lanczos_tol=1e-12,
-                 maxrestart=3, weighting="sqrtdim", jacobi_tol=1e-14, jacobi_max_sweeps=40, shard=None):
+                 maxrestart=3, weighting="sqrtdim", jacobi_tol=1e-14, jacobi_max_sweeps=40, shard=None,
+                 left_env=None, right_env=None):
         self.ops, self.mpo = ops, mpo
         self.L = len(mpo)
         self.chi_full, self.cutoff, self.weighting = chi_full, cutoff, weighting
@@ -77,10 +78,20 @@ class DMRG2:
         self.Lbuf = [None] * (self.L + 1)
         self.Rlay = [None] * (self.L + 1)
         self.Rbuf = [None] * (self.L + 1)
-        self.Llay[0] = EnvLayout.build("L", self.bonds[0], mpo[0].left)
-        self.Rlay[self.L] = EnvLayout.build("R", self.bonds[self.L], mpo[self.L - 1].right)
-        self.Lbuf[0] = ops.zeros_z(1)
-        self.Rbuf[self.L] = ops.zeros_z(1)
+        # boundaries: an open end (no environment blocks: only the implicit identity level), or -- for a window
+        # inside a larger system (idmrg.py) -- the (EnvLayout, device buffer) of the block beyond that end
+        if left_env is None:
+            self.Llay[0] = EnvLayout.build("L", self.bonds[0], mpo[0].left)
+            self.Lbuf[0] = ops.zeros_z(max(self.Llay[0].size, 1))
+        else:
+            self.Llay[0], self.Lbuf[0] = left_env
+            assert self.Llay[0].bond == self.bonds[0] and self.Llay[0].levels == list(mpo[0].left)
+        if right_env is None:
+            self.Rlay[self.L] = EnvLayout.build("R", self.bonds[self.L], mpo[self.L - 1].right)
+            self.Rbuf[self.L] = ops.zeros_z(max(self.Rlay[self.L].size, 1))
+        else:
+            self.Rlay[self.L], self.Rbuf[self.L] = right_env
+            assert self.Rlay[self.L].bond == self.bonds[self.L] and self.Rlay[self.L].levels == list(mpo[self.L - 1].right)
         for i in range(self.L - 1, 0, -1):
             self._right_env(i)
         self.energy = None

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .planner import full_bonds, fuse
+from .planner import full_bonds, fuse, split
 
 
 def random_mps(nsites, target, max_dimension, seed=1234, max_twoS=6):
@@ -33,6 +33,67 @@ def random_mps(nsites, target, max_dimension, seed=1234, max_twoS=6):
             M = rng.standard_normal((nc, ncols)) + 1j * rng.standard_normal((nc, ncols))
             q, _ = np.linalg.qr(M.conj().T)
             M = q.conj().T
+            off = 0
+            for (s, b) in cols:
+                T[(c, s, b)] = np.ascontiguousarray(M[:, off:off + br[b]])
+                off += br[b]
+        tensors[i] = T
+    for i in range(nsites):
+        tensors[i] = {k: v for k, v in tensors[i].items() if k[0] in bonds[i] and k[2] in bonds[i + 1]}
+    return bonds, tensors
+
+
+def random_window(nsites, bond_left, bond_right, max_dimension, seed=1234, max_twoS=8):
+    """random state of `nsites` sites between two FIXED boundary bond tables (the bases of the left and right
+    environment blocks of an iDMRG window, hubbardtn_amd/idmrg.py).  Internal virtual spaces = sectors reachable
+    from the left table and co-reachable from the right one, capped per sector; sites 1.. are right-canonical,
+    site 0 carries the (unnormalised) centre.  Same return convention as random_mps."""
+    rng = np.random.default_rng(seed)
+    fwd = [dict(bond_left)]
+    for _ in range(nsites):
+        nxt = {}
+        for c, n in fwd[-1].items():
+            for s in range(3):
+                for b in fuse(c, s):
+                    nxt[b] = min(nxt.get(b, 0) + n, 1 << 30)
+        fwd.append(nxt)
+    bwd = [None] * (nsites + 1)
+    bwd[nsites] = dict(bond_right)
+    for i in range(nsites - 1, -1, -1):
+        prv = {}
+        for b, n in bwd[i + 1].items():
+            for s in range(3):
+                for c in split(b, s):
+                    prv[c] = min(prv.get(c, 0) + n, 1 << 30)
+        bwd[i] = prv
+    bonds = []
+    for i in range(nsites + 1):
+        if i == 0:
+            bonds.append(dict(bond_left))
+        elif i == nsites:
+            bonds.append(dict(bond_right))
+        else:
+            bonds.append({c: min(fwd[i][c], bwd[i][c], max_dimension) for c in fwd[i]
+                          if c in bwd[i] and c[1] <= max_twoS})
+    tensors = [None] * nsites
+    for i in range(nsites - 1, -1, -1):
+        bl, br = bonds[i], bonds[i + 1]
+        T = {}
+        for c in sorted(bl):
+            cols = [(s, b) for s in range(3) for b in fuse(c, s) if b in br]
+            ncols = sum(br[b] for (_, b) in cols)
+            if ncols == 0:
+                if i > 0:
+                    del bl[c]
+                continue
+            nc = bl[c]
+            if i > 0:
+                nc = min(nc, ncols)
+                bl[c] = nc
+            M = rng.standard_normal((nc, ncols)) + 1j * rng.standard_normal((nc, ncols))
+            if i > 0:                                   # right-canonical: orthonormal rows
+                q, _ = np.linalg.qr(M.conj().T)
+                M = q.conj().T
             off = 0
             for (s, b) in cols:
                 T[(c, s, b)] = np.ascontiguousarray(M[:, off:off + br[b]])
