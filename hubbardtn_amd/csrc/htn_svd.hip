@@ -15,9 +15,9 @@
 //     and both columns stay in registers between the dot products and the rotation;
 //   * the matrix lives in LDS when it fits the dynamic LDS window (round latency ~ LDS instead of L2),
 //     otherwise in global memory (L2 resident: a few hundred KB);
-//   * sweeps stop early through the quadratic convergence of cyclic Jacobi: once the largest
-//     |a.b| / (|a||b|) seen in a sweep is below 1e-8, ONE more sweep brings it below 1e-16, so the final
-//     "checking" sweep of the textbook loop is skipped.
+//   * sweeps stop early through the quadratic convergence of cyclic Jacobi: a sweep whose largest squared
+//     cosine, seen BEFORE the rotations, is below 0.1 tol leaves less than tol^2 behind, so neither the
+//     textbook's final "checking" sweep nor the sweep before it is run.
 #define JAC_THREADS 1024
 #define JAC_MAXEL 8           // column elements per lane kept in registers: m <= GS * JAC_MAXEL
 
@@ -100,7 +100,6 @@ __device__ __forceinline__ int jacobi_sweeps(double2* g, double2* __restrict__ v
     const int np = n + (n & 1);      // padded to even; index np-1 == n is a bye when n is odd
     int sweeps = 0;
     bool done = (n < 2);
-    bool last = false;
     while (!done && sweeps < max_sweeps) {
         if (tid == 0) *s_ratio = 0.0;
         __syncthreads();
@@ -129,8 +128,10 @@ __device__ __forceinline__ int jacobi_sweeps(double2* g, double2* __restrict__ v
         __syncthreads();
         const double mx = *s_ratio;  // max over the sweep of the SQUARED cosine between column pairs
         ++sweeps;
-        done = last || mx <= tol * tol;
-        last = mx < 1e-16;           // quadratic convergence: the next sweep is the final one
+        // mx is what the sweep SAW before its rotations; by the quadratic convergence of cyclic Jacobi the sweep
+        // leaves about C mx^2 behind (C = 0.005 .. 0.2 measured on Schmidt-type spectra).  A sweep that saw
+        // no squared cosine above 0.1 tol has therefore left < tol^2: no checking sweep afterwards.
+        done = mx <= fmax(tol * tol, 0.1 * tol);
         __syncthreads();
     }
     return done ? sweeps : -sweeps;
@@ -212,7 +213,6 @@ __device__ __forceinline__ int jacobi_sweeps_pad(C cols, int n, int max_sweeps, 
     const double tol2 = tol * tol;
     int sweeps = 0;
     bool done = (n < 2);
-    bool last = false;
     while (!done && sweeps < max_sweeps) {
         if (tid == 0) *s_ratio = 0.0;
         __syncthreads();
@@ -241,8 +241,7 @@ __device__ __forceinline__ int jacobi_sweeps_pad(C cols, int n, int max_sweeps, 
         __syncthreads();
         const double mx = *s_ratio;  // max over the sweep of the SQUARED cosine between column pairs
         ++sweeps;
-        done = last || mx <= tol2;
-        last = mx < 1e-16;           // quadratic convergence: the next sweep is the final one
+        done = mx <= fmax(tol2, 0.1 * tol);                // quadratic convergence, see jacobi_sweeps
         __syncthreads();
     }
     return done ? sweeps : -sweeps;
@@ -1121,12 +1120,37 @@ __global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__
     if (tid == 0) atomicMax(&ratio_bits[it.blk], first_bits);
 }
 
+// after every outer sweep: convergence bookkeeping of the large blocks ON THE DEVICE (one thread per block), so
+// the host never has to answer before the next sweep can start.  active_out is host-pinned: the host reads it
+// one sweep late (the next sweep is already enqueued; if everything had converged its visits return at once).
+__global__ void k_jacobi_check(unsigned long long* __restrict__ ratio_bits, int* __restrict__ done,
+                               int* __restrict__ sweeps, int nl, double thr, int* __restrict__ active_out) {
+    __shared__ int s_active;
+    if (threadIdx.x == 0) s_active = 0;
+    __syncthreads();
+    for (int li = threadIdx.x; li < nl; li += blockDim.x) {
+        if (!done[li]) {
+            const double mx = __longlong_as_double((long long)ratio_bits[li]);
+            sweeps[li] += 1;
+            if (mx <= thr) done[li] = 1;
+            else atomicAdd(&s_active, 1);
+        }
+        ratio_bits[li] = 0ull;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *active_out = s_active;
+        __threadfence_system();
+    }
+}
+
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_finish(double2* __restrict__ G, const double2* __restrict__ Vj,
                                                                double* __restrict__ S,
                                                                const htn_svd_block* __restrict__ desc,
                                                                const int* __restrict__ large_ids,
                                                                const int* __restrict__ perm,
-                                                               const int* __restrict__ sweeps, int* __restrict__ info) {
+                                                               const int* __restrict__ sweeps,
+                                                               const int* __restrict__ done, int* __restrict__ info) {
     const int b = large_ids[blockIdx.x];
     const htn_svd_block D = desc[b];
     const int m = D.m, n = D.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1145,7 +1169,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_finish(double2* __restri
         sn = wave_sum(sn);
         if (lane == 0) S[D.s_off + j] = sqrt(sn);
     }
-    if (tid == 0) info[b] = sweeps[blockIdx.x];
+    if (tid == 0) info[b] = done[blockIdx.x] ? sweeps[blockIdx.x] : -sweeps[blockIdx.x];
 }
 
 // thread-local device scratch of the multi-launch path (grown on demand)
@@ -1155,7 +1179,7 @@ struct JacScratch {
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
     hipStream_t aux = nullptr;          // forked stream: small blocks run beside the large-block pipeline
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sweep[2] = {nullptr, nullptr};
 };
 static thread_local JacScratch g_js;
 
@@ -1174,6 +1198,8 @@ static int js_reserve(size_t dev_bytes, size_t pin_bytes) {
         HIP_TRY(hipStreamCreateWithFlags(&g_js.aux, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&g_js.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g_js.ev_join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g_js.ev_sweep[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g_js.ev_sweep[1], hipEventDisableTiming));
     }
     return 0;
 }
@@ -1265,7 +1291,8 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     const size_t off_ratio = (off_zero + sizeof(double) * nl + 7) / 8 * 8, off_done = off_ratio + 8 * nl;
     const size_t off_sw = off_done + sizeof(int) * nl, off_items = (off_sw + sizeof(int) * nl + 31) / 32 * 32;
     const size_t dev_bytes = off_items + sizeof(JacPairItem) * n_items;
-    if (js_reserve(dev_bytes, sizeof(JacPairItem) * n_items + 64 * nl + 4 * n_blocks + 128)) return 1;
+    if (js_reserve(dev_bytes, sizeof(JacPairItem) * n_items + 16 * nl + 4 * n_blocks + 4 * (size_t)(max_sweeps + 1) + 128))
+        return 1;
     char* d = (char*)g_js.dev;
     int* d_ids = (int*)(d + off_ids);
     int* d_slot = (int*)(d + off_slot);
@@ -1275,14 +1302,12 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     int* d_done = (int*)(d + off_done);
     int* d_sw = (int*)(d + off_sw);
     JacPairItem* d_items = (JacPairItem*)(d + off_items);
-    // pinned staging: [items | ids | ratio(host) | done(host) | sweeps(host)]
+    // pinned staging: [items | ids | slot of every block | active count per sweep (written by the device)]
     char* h = (char*)g_js.pinned;
     JacPairItem* h_items = (JacPairItem*)h;
     int* h_ids = (int*)(h + sizeof(JacPairItem) * n_items);
-    double* h_ratio = (double*)((char*)h_ids + 16 * ((nl * 4 + 15) / 16));
-    int* h_done = (int*)(h_ratio + nl);
-    int* h_sw = h_done + nl;
-    int* h_slot = h_sw + nl;
+    int* h_slot = (int*)((char*)h_ids + 16 * ((nl * 4 + 15) / 16));
+    volatile int* h_active = (volatile int*)(h_slot + n_blocks);
     for (int b = 0; b < n_blocks; ++b) h_slot[b] = -1;
     for (int li = 0; li < nl; ++li) h_slot[large[li]] = li;
     std::vector<size_t> r_off(rounds.size());
@@ -1293,11 +1318,8 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
             for (auto& it : rounds[r]) h_items[pos++] = it;
         }
     }
-    for (int li = 0; li < nl; ++li) {
-        h_ids[li] = large[li];
-        h_done[li] = 0;
-        h_sw[li] = 0;
-    }
+    for (int li = 0; li < nl; ++li) h_ids[li] = large[li];
+    for (int k = 0; k <= max_sweeps; ++k) h_active[k] = 1;
     HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(JacPairItem) * n_items, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_ids, h_ids, sizeof(int) * nl, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_slot, h_slot, sizeof(int) * n_blocks, hipMemcpyHostToDevice, st));
@@ -1317,35 +1339,29 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
                            d_perm, d_zero);
     }
     const size_t gram_lds_bytes = (size_t)(16 * (max_mp + 1) + 4 * 16 * JG_LD) * sizeof(double2);
-    std::vector<char> last(nl, 0);
-    bool all_done = false;
-    for (int sweep = 0; sweep < max_sweeps && !all_done; ++sweep) {
-        HIP_TRY(hipMemsetAsync(d_ratio, 0, 8 * nl, st));
+    // sweeps are enqueued one ahead of the host's knowledge (depth-1 pipeline, like htn_lanczos_z): the device
+    // decides convergence itself (k_jacobi_check), the host only learns when to stop enqueuing
+    HIP_TRY(hipMemsetAsync(d_ratio, 0, 8 * nl, st));
+    HIP_TRY(hipMemsetAsync(d_sw, 0, sizeof(int) * nl, st));
+    const double thr = std::max(tol * tol, 0.1 * tol);          // quadratic convergence, see jacobi_sweeps
+    auto enqueue_sweep = [&](int sweep) {
         for (size_t r = 0; r < rounds.size(); ++r)
-            if (!rounds[r].empty()) {
+            if (!rounds[r].empty())
                 hipLaunchKernelGGL(k_jacobi_pairs_gram, dim3((unsigned)rounds[r].size()), dim3(256), gram_lds_bytes, st,
                                    (double2*)Vj, desc, d_ids, d_items + r_off[r], d_zero, d_ratio, d_done, tol, 1);
-            }
-        HIP_TRY(hipMemcpyAsync(h_ratio, d_ratio, 8 * nl, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        all_done = true;
-        for (int li = 0; li < nl; ++li) {
-            if (h_done[li]) continue;
-            const double mx = h_ratio[li];
-            h_sw[li] += 1;
-            const bool dn = last[li] || mx <= tol * tol;
-            last[li] = mx < 1e-16;
-            h_done[li] = dn ? 1 : 0;
-            if (!dn) all_done = false;
-        }
-        HIP_TRY(hipMemcpyAsync(d_done, h_done, sizeof(int) * nl, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_jacobi_check, dim3(1), dim3(64), 0, st, d_ratio, d_done, d_sw, nl, thr,
+                           (int*)h_active + sweep);
+        return hipEventRecord(g_js.ev_sweep[sweep & 1], st);
+    };
+    if (max_sweeps > 0) HIP_TRY(enqueue_sweep(0));
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (sweep + 1 < max_sweeps) HIP_TRY(enqueue_sweep(sweep + 1));
+        HIP_TRY(hipEventSynchronize(g_js.ev_sweep[sweep & 1]));
+        if (h_active[sweep] == 0) break;
     }
-    for (int li = 0; li < nl; ++li)
-        if (!h_done[li]) h_sw[li] = -h_sw[li];
-    HIP_TRY(hipMemcpyAsync(d_sw, h_sw, sizeof(int) * nl, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamWaitEvent(st, g_js.ev_join, 0));
     hipLaunchKernelGGL(k_jacobi_finish, dim3(nl), dim3(JAC_THREADS), 0, st, (double2*)G, (const double2*)Vj, S, desc,
-                       d_ids, d_perm, d_sw, info_dev);
+                       d_ids, d_perm, d_sw, d_done, info_dev);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));      // the pinned staging block is reused by the next call
     return 0;
