@@ -32,6 +32,7 @@ class HipOps:
         self.arch = name.value.decode()
         self.cu_count = cus.value
         self._dots_scratch = None
+        self._stream_ptr = None
         self.event_log = None        # bench.py: list of (start_event, end_event, tag, flops)
 
     # ---- memory -----------------------------------------------------------------------------
@@ -50,8 +51,32 @@ class HipOps:
     def to_device(self, arr: np.ndarray):
         arr = np.ascontiguousarray(arr)
         if arr.dtype.fields is not None:            # struct arrays travel as bytes
-            return self.torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
-        return self.torch.from_numpy(arr.copy()).to(self.device)
+            arr = arr.view(np.uint8)
+        # a pageable-memory .to(device) returns after the source has been staged: no defensive copy needed
+        return self.torch.from_numpy(arr).to(self.device)
+
+    def to_device_packed(self, arrays):
+        """several small host arrays -> ONE host-to-device copy; returns device views (one per array, 16-byte
+        aligned inside the packed buffer).  The per-bond bookkeeping arrays are a few hundred bytes each and a
+        separate copy costs ~20 us of host time apiece."""
+        raws = [np.ascontiguousarray(a).view(np.uint8).reshape(-1) for a in arrays]
+        offs, pos = [], 0
+        for r in raws:
+            offs.append(pos)
+            pos += (r.size + 15) // 16 * 16
+        buf = np.zeros(max(pos, 16), dtype=np.uint8)
+        for r, o in zip(raws, offs):
+            buf[o:o + r.size] = r
+        dev = self.torch.from_numpy(buf).to(self.device)
+        out = []
+        for a, r, o in zip(arrays, raws, offs):
+            v = dev[o:o + max(r.size, 1)]
+            a = np.asarray(a)
+            if a.dtype.fields is None and a.dtype != np.uint8:
+                v = v.view(getattr(self.torch, {"int32": "int32", "int64": "int64", "float64": "float64",
+                                                 "complex128": "complex128"}[a.dtype.name])) if r.size else v
+            out.append(v)
+        return out
 
     def to_host(self, t) -> np.ndarray:
         return t.cpu().numpy()
@@ -66,7 +91,16 @@ class HipOps:
         self.torch.cuda.current_stream().synchronize()
 
     def _stream(self):
-        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+        # the launch stream is looked up once (torch.cuda.current_stream() costs ~10 us per call, ~1000 calls per
+        # sweep); use_stream() re-binds when the caller switches torch's current stream
+        s = self._stream_ptr
+        if s is None:
+            s = self._stream_ptr = C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+        return s
+
+    def use_stream(self):
+        """re-read torch's current stream (call after torch.cuda.set_stream / inside a torch.cuda.stream block)"""
+        self._stream_ptr = None
 
     @staticmethod
     def _p(t):
@@ -75,7 +109,8 @@ class HipOps:
     # ---- kernels ----------------------------------------------------------------------------
     def upload_tasks(self, tasks):
         """tasks: planner.Tasks -> (tiles_dev, ntiles, segs_dev)"""
-        return (self.to_device(tasks.tiles), tasks.ntiles, self.to_device(tasks.segs))
+        tiles, segs = self.to_device_packed([tasks.tiles, tasks.segs])
+        return (tiles, tasks.ntiles, segs)
 
     def grouped_gemm(self, bufs, dev_tasks, tag=None, flops=0):
         tiles, ntiles, segs = dev_tasks

@@ -277,13 +277,13 @@ class DMRG2:
         offA, offB = 0, layA.size
         iso_g, cen_g, iso_v, idx, cen_tasks = pl.plan_finalize(tl, sp, order, keep, layA, layB, placement, offA, offB)
         out = ops.zeros_z(max(layA.size + layB.size, 1))
-        idx_d = ops.to_device(idx)
+        idx_d, iso_g_d, cen_g_d, iso_v_d = ops.to_device_packed([idx, iso_g, cen_g, iso_v])    # one upload
         if len(iso_g):
-            ops.batched_copy(out, G, idx_d, S, ops.to_device(iso_g), len(iso_g), 1.0)
+            ops.batched_copy(out, G, idx_d, S, iso_g_d, len(iso_g), 1.0)
         if len(cen_g):
-            ops.batched_copy(out, G, idx_d, S, ops.to_device(cen_g), len(cen_g), 1.0 / nrm)
+            ops.batched_copy(out, G, idx_d, S, cen_g_d, len(cen_g), 1.0 / nrm)
         if len(iso_v):
-            ops.batched_copy(out, Vj, idx_d, S, ops.to_device(iso_v), len(iso_v), 1.0)
+            ops.batched_copy(out, Vj, idx_d, S, iso_v_d, len(iso_v), 1.0)
         if cen_tasks is not None:
             cen_tasks.segs["alpha_re"] *= 1.0 / nrm
             ops.grouped_gemm(self._bufs(x=x, s1=out, y=out), ops.upload_tasks(cen_tasks))

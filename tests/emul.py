@@ -31,6 +31,9 @@ class NumpyOps:
     def to_device(self, arr):
         return np.array(arr, copy=True)
 
+    def to_device_packed(self, arrays):
+        return [np.array(a, copy=True) for a in arrays]
+
     def to_host(self, t):
         return np.array(t, copy=True)
 
