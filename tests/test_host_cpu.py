@@ -267,3 +267,34 @@ def test_symbolic_apply_plan_equals_loop_plan():
         ref = pl.plan_apply(tl, Ll, Rl, mpo[i], mpo[i + 1])
         new = pl.plan_apply_cached(tl, Ll, Rl, mpo[i], mpo[i + 1])
         assert same(ref[0], new[0]) and same(ref[1], new[1]) and ref[2:] == new[2:], i
+
+
+def test_vectorised_finalize_plan_equals_general_path():
+    """plan_finalize's column-wise fast path (default staging) == the per-block general path, both placements"""
+    import inspect
+    from hubbardtn_amd import planner as pl
+    rng = np.random.default_rng(1)
+    tab = {(2, 0): 2, (2, 2): 1, (3, 1): 12, (3, 3): 3, (4, 0): 23, (4, 2): 24, (4, 4): 4, (5, 1): 33, (5, 3): 24,
+           (6, 0): 14, (6, 2): 22, (6, 4): 13, (7, 1): 13, (7, 3): 4, (8, 0): 3}
+    bl = pl.Bond({(N + 5, j): n for (N, j), n in tab.items()})
+    br = pl.Bond({(N + 7, j): n for (N, j), n in tab.items()})
+    tl = pl.ThetaLayout.build(bl, br)
+    code = inspect.getsource(pl.plan_finalize).replace(
+        "    if not any(sp.accumulate):\n        return _plan_finalize_fast(tl, sp, order, keep, layA, layB, placement, offA, offB)\n", "")
+    assert "_plan_finalize_fast" not in code
+    ns = dict(pl.__dict__)
+    exec(code, ns)
+    general = ns["plan_finalize"]
+    for placement in ("right", "left"):
+        sp = pl.plan_svd(tl, placement)
+        svals = {c: np.sort(rng.random(int(sp.desc[i]["n"])))[::-1] for i, c in enumerate(sp.mids)}
+        order = {c: rng.permutation(len(v)) for c, v in svals.items()}
+        keep, tw, nrm = pl.truncate(svals, 200, 0.0, "sqrtdim")
+        mid = pl.Bond({c: k for c, k in keep.items() if k > 0})
+        layA, layB = pl.SiteLayout.build("L", bl, mid), pl.SiteLayout.build("R", mid, br)
+        new = pl.plan_finalize(tl, sp, order, keep, layA, layB, placement, 0, layA.size)
+        ref = general(tl, sp, order, keep, layA, layB, placement, 0, layA.size)
+        for a, b in zip(ref[:4], new[:4]):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+        assert ref[4].tiles.tobytes() == new[4].tiles.tobytes() and ref[4].segs.tobytes() == new[4].segs.tobytes()
+        assert ref[4].flops == new[4].flops
