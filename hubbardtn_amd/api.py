@@ -219,3 +219,23 @@ def dim_state(psi: FiniteMPS):
     if isinstance(psi, InfiniteMPS):
         return psi.bond_dimensions()
     return psi.engine.bond_dims()[1:]
+
+
+def density_state(psi):
+    """electrons per site <n_i> (src:1475-1523): all L sites of a finite chain, the unit cell of an infinite one
+    (its sum / len equals the filling P/Q, the check at test/OB.jl:97-99)"""
+    if isinstance(psi, InfiniteMPS):
+        if psi.result is None:
+            raise RuntimeError("run find_groundstate first")
+        T = psi.result.unit_cell
+        n, _ = psi.result.engine.site_occupations()
+        return n[T // 2:T // 2 + T]
+    return psi.engine.site_occupations()[0]
+
+
+def double_occupancy(psi):
+    """<n_up n_dn> per site, same conventions as density_state"""
+    if isinstance(psi, InfiniteMPS):
+        T = psi.result.unit_cell
+        return psi.result.engine.site_occupations()[1][T // 2:T // 2 + T]
+    return psi.engine.site_occupations()[1]

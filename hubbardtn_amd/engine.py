@@ -220,9 +220,10 @@ class DMRG2:
         return stages, flops, nbytes, ntiles, nsegs
 
     # ---- one bond ---------------------------------------------------------------------------------
-    def update_bond(self, i, direction, placement):
+    def update_bond(self, i, direction, placement, optimise=True):
         """optimise sites (i, i+1); placement 'right': A_i = U, centre S V^H on i+1 (+ left env);
-        'left': centre U S on i, B_{i+1} = V^H (+ right env)."""
+        'left': centre U S on i, B_{i+1} = V^H (+ right env).  optimise=False only moves the centre: the
+        eigensolver stops after its first step (x = theta normalised, E = <theta|H|theta>)."""
         t0 = time.perf_counter()
         ops = self.ops
         bl, br = self.bonds[i], self.bonds[i + 2]
@@ -241,7 +242,7 @@ class DMRG2:
         if self.profile:
             ops.sync()
         t_plan = time.perf_counter() - t0
-        E, nmv, res = ops.lanczos(stages, BUF_X, BUF_Y, V, n, kd, self.lanczos_tol, self.maxrestart,
+        E, nmv, res = ops.lanczos(stages, BUF_X, BUF_Y, V, n, kd, self.lanczos_tol if optimise else 1e300, self.maxrestart,
                                   zero_y=self.shard is not None,
                                   exchange=self.shard[2] if self.shard is not None else None)
         if self.profile:
@@ -320,6 +321,31 @@ class DMRG2:
         for i in range(L - 3, -1, -1):
             self.update_bond(i, -1, "left")
         return self.energy
+
+    def site_occupations(self):
+        """-> (n, d): <n_i> and the double occupancy <n_up n_dn>_i of every site (density_state, src:1495-1523).
+        Call after sweep() (centre on site 0, sites >= 1 right-canonical).  The centre is carried through the chain
+        without optimisation; with the centre on site i the probability of site multiplet s is the squared norm
+        of the (., s, .) blocks (tilde normalisation), and n = P(single) + 2 P(double)."""
+        L = self.L
+        n, d = np.zeros(L), np.zeros(L)
+
+        def read(i):
+            p = np.zeros(3)
+            for (l, s, r), blk in self.download_site(i).items():
+                p[s] += float(np.sum(np.abs(blk) ** 2))
+            p /= p.sum()
+            n[i], d[i] = p[1] + 2.0 * p[2], p[2]
+        saved = (self.chi_full, self.cutoff, self.stats, self.energy, dict(self.spectra))
+        self.cutoff = 0.0                                       # moving the centre must not truncate by value
+        read(0)
+        for i in range(L - 1):
+            self.update_bond(i, +1, "right", optimise=False)
+            read(i + 1)
+        for i in range(L - 2, -1, -1):                          # back to the post-sweep convention
+            self.update_bond(i, -1, "left", optimise=False)
+        self.chi_full, self.cutoff, self.stats, self.energy, self.spectra = saved
+        return n, d
 
     def bond_dims(self):
         """`dim_state` analogue (src/HubbardFunctions.jl:1399-1405): TensorKit dim of each bond"""
