@@ -239,3 +239,37 @@ def double_occupancy(psi):
         T = psi.result.unit_cell
         return psi.result.engine.site_occupations()[1][T // 2:T // 2 + T]
     return psi.engine.site_occupations()[1]
+
+
+def TruncState(simul: Simulation, trunc_dim: int, trunc_scheme: int = 0, L: int | None = None, **kw):
+    """truncated approximation of the ground state at bond dimension `trunc_dim` (TensorKit dim units), src:1351-1367.
+    trunc_scheme 1 = SvdCut (truncate by SVD only); 0 = VUMPSSvdCut (truncate, then re-optimise variationally at
+    that dimension -- here: further two-site sweeps with truncdim(trunc_dim)).  Finite chains (L given); for the
+    infinite chain scheme 0 = IDMRG2 at truncdim(trunc_dim)."""
+    if trunc_dim <= 0:
+        raise ValueError("trunc_dim should be a positive integer.")
+    if trunc_scheme not in (0, 1):
+        raise ValueError("trunc_scheme should be either 0 (VUMPSSvdCut) or 1 (SvdCut).")
+    L = L or simul.kwargs.get("L")
+    if L is None:
+        if trunc_scheme == 1:
+            raise NotImplementedError("SvdCut of an infinite MPS needs the uniform gauge (not on the hot path)")
+        d = compute_groundstate(simul, chi=trunc_dim, **kw)
+        return {"ψ_trunc": d["groundstate"], "envs_trunc": d["environments"]}
+    d = produce_groundstate(simul, L=L, **kw)
+    psi = d["groundstate"]
+    eng = psi.engine
+    eng.svd_cut(trunc_dim)
+    if trunc_scheme == 0:
+        E_prev = None
+        for _ in range(kw.get("maxiter", 20)):
+            E = eng.sweep()
+            if E_prev is not None and abs(E - E_prev) / psi.L < kw.get("tol", 1e-6):
+                break
+            E_prev = E
+    return {"ψ_trunc": psi, "envs_trunc": Environments(eng)}
+
+
+def produce_TruncState(simul: Simulation, trunc_dim: int, trunc_scheme: int = 0, force: bool = False, **kw):
+    """src:1378-1385 without the DrWatson disk cache"""
+    return TruncState(simul, trunc_dim, trunc_scheme=trunc_scheme, **kw)

@@ -347,6 +347,19 @@ class DMRG2:
         self.chi_full, self.cutoff, self.stats, self.energy, self.spectra = saved
         return n, d
 
+    def svd_cut(self, chi_full):
+        """truncate every bond to truncdim(chi_full) by SVD alone (MPSKit `changebonds(psi, SvdCut(trscheme))`,
+        used at src:1363-1365): one pass of centre moves without optimisation at the new limit.  Returns the
+        energy <psi|H|psi> of the truncated state.  Call after sweep()."""
+        saved = (self.cutoff, self.stats)
+        self.chi_full, self.cutoff = int(chi_full), 0.0
+        for i in range(self.L - 1):
+            self.update_bond(i, +1, "right" if i < self.L - 2 else "left", optimise=False)
+        for i in range(self.L - 3, -1, -1):
+            self.update_bond(i, -1, "left", optimise=False)
+        self.cutoff, self.stats = saved
+        return self.energy
+
     def bond_dims(self):
         """`dim_state` analogue (src/HubbardFunctions.jl:1399-1405): TensorKit dim of each bond"""
         return [b.dim_full for b in self.bonds]

@@ -67,3 +67,19 @@ def test_infinite_chain_filling_is_conserved():
     n = api.density_state(d["groundstate"])
     assert len(n) == 4 and abs(n.sum() / 4 - 1.5) < 5e-3
     assert np.all(n > 1.0) and np.all(n < 2.0)
+
+
+def test_truncstate_schemes():
+    """produce_TruncState (src:1351-1385): SvdCut (scheme 1) truncates only, scheme 0 re-optimises at the cut
+    dimension: E_exact <= E(scheme 0) <= E(scheme 1), all bonds within trunc_dim"""
+    model = api.OB_Sim([1.0], [4.0], 0.0, 1, 1, 4.0, 8)
+    L, D = 10, 40
+    Eref, _ = ed.SectorED(L, 5, 5, [1.0], [4.0]).ground_state()
+    E = {}
+    for scheme in (1, 0):
+        d = api.produce_TruncState(model, D, trunc_scheme=scheme, L=L, tol=1e-9)
+        psi = d["ψ_trunc"]
+        assert max(api.dim_state(psi)) <= D
+        E[scheme] = float(np.sum(api.expectation_value(psi, None)))
+    assert Eref - 1e-9 <= E[0] <= E[1] + 1e-12
+    assert E[1] - Eref < 5e-3 and E[0] - Eref < 2e-3

@@ -160,7 +160,8 @@ def test_planner_truncate_matches_oracle_rule():
 
 def test_api_surface_keeps_reference_names():
     for name in ("OB_Sim", "MB_Sim", "produce_groundstate", "compute_groundstate", "find_groundstate",
-                 "initialize_mps", "hamiltonian", "dim_state", "expectation_value", "truncdim", "truncbelow", "DMRG2"):
+                 "initialize_mps", "hamiltonian", "dim_state", "expectation_value", "truncdim", "truncbelow", "DMRG2",
+                 "IDMRG2", "density_state", "TruncState", "produce_TruncState"):
         assert hasattr(api, name)
     sim = api.OB_Sim([1.0], [4.0], 0.0, 1, 1, 2.0, 6)
     H = api.hamiltonian(sim, L=6)
