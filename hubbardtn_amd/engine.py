@@ -166,7 +166,7 @@ class DMRG2:
 
         def build():
             Lnew = EnvLayout.build("L", self.bonds[i + 1], self.mpo[i].right)
-            t1, t2, zsize = pl.plan_left_env(self.Llay[i], lay, self.mpo[i], Lnew)
+            t1, t2, zsize = pl.plan_env_cached("L", self.Llay[i], lay, self.mpo[i], Lnew)
             return Lnew, ops.upload_tasks(t1), ops.upload_tasks(t2), zsize, t1.flops + t2.flops
         Lnew, d1, d2, zsize, flops = self._cached(("lenv", i, self.bonds[i].key(), self.bonds[i + 1].key()), build)
         z = ops.empty_z(max(zsize, 1))
@@ -184,7 +184,7 @@ class DMRG2:
 
         def build():
             Rnew = EnvLayout.build("R", self.bonds[i], self.mpo[i].left)
-            t1, t2, zsize = pl.plan_right_env(self.Rlay[i + 1], lay, self.mpo[i], Rnew)
+            t1, t2, zsize = pl.plan_env_cached("R", self.Rlay[i + 1], lay, self.mpo[i], Rnew)
             return Rnew, ops.upload_tasks(t1), ops.upload_tasks(t2), zsize, t1.flops + t2.flops
         Rnew, d1, d2, zsize, flops = self._cached(("renv", i, self.bonds[i].key(), self.bonds[i + 1].key()), build)
         z = ops.empty_z(max(zsize, 1))

@@ -767,6 +767,193 @@ def plan_right_env(Rl: EnvLayout, lay: SiteLayout, W, Rnew: EnvLayout):
     return t1.finalize(), t2.finalize(), zoff
 
 
+# ---- dimension-independent environment-update plans (same idea as ApplySym) -------------------------
+class EnvSym:
+    """index structure of plan_left_env / plan_right_env; instantiate() fills in offsets and sizes"""
+    __slots__ = ("side", "out_has", "out_mat", "zq", "b1_panel", "b1_lb", "s1")
+
+    @staticmethod
+    def build(side, Eold, lay, W, Enew):
+        left = side == "L"
+        assert lay.kind == ("L" if left else "R")
+        matidx = {k: i for i, k in enumerate(lay.mats)}
+        lbidx = {k: i for i, k in enumerate(lay.blocks)}
+        eidx = {k: i for i, k in enumerate(Eold.blocks)}
+        sym = EnvSym()
+        sym.side = side
+        out_has, out_mat, zq = [], [], []
+        b1_panel, b1_lb, b1_key = [], [], {}
+        ypanel = {}
+        for q, key in enumerate(Enew.blocks):
+            if left:
+                cp, wp, c = key
+            else:
+                c, wp, cp = key
+            has = cp in lay.mats and c in lay.mats
+            out_has.append(has)
+            out_mat.append(matidx[cp] if has else 0)
+            if not has:
+                continue
+            p_ = len(zq)
+            ypanel[key] = p_
+            zq.append(q)
+            for g in lay.mats[cp][3]:
+                if left:
+                    (ap, sp) = g
+                    k1, lbk = (cp, wp, c, ap, sp), (ap, sp, cp)
+                else:
+                    (sp, bp) = g
+                    k1, lbk = (c, wp, cp, sp, bp), (cp, sp, bp)
+                b1_key[k1] = len(b1_panel)
+                b1_panel.append(p_)
+                b1_lb.append(lbidx[lbk])
+        segs = [dict() for _ in b1_panel]
+        nfin_r, nfin_l = len(W.right) - 1, len(W.left) - 1
+        for (wl, wr, name, coef) in W.entries:
+            if left and wr == 0 and len(W.right) > 1:
+                continue
+            if (not left) and wl == nfin_l and len(W.left) > 1:
+                continue
+            kop, dN, red = SITE_OPS[name]
+            kl, kr = W.left[wl][1], W.right[wr][1]
+            for blk, bi in lbidx.items():
+                if left:
+                    a, s_, c = blk
+                else:
+                    c, s_, b = blk
+                for sp in range(3):
+                    r = red[sp, s_]
+                    if r == 0.0:
+                        continue
+                    if left:
+                        aps = [a] if wl == 0 else Eold.by_ket.get((wl, a), [])
+                        for ap in aps:
+                            for cp in fuse(ap, sp):
+                                if (cp, wr, c) not in ypanel or (ap, sp, cp) not in lay.blocks:
+                                    continue
+                                cf = coef_left(ap[1], kl, a[1], SITE_MULT[sp][1], SITE_MULT[s_][1], kop, cp[1], kr, c[1])
+                                alpha = cf * r * coef
+                                if alpha == 0.0:
+                                    continue
+                                d = segs[b1_key[(cp, wr, c, ap, sp)]]
+                                k = (_KIND_C, bi, 0) if wl == 0 else (_KIND_L, eidx[(ap, wl, a)], bi)
+                                d[k] = d.get(k, 0.0) + alpha
+                    else:
+                        bps = [b] if wr == nfin_r else Eold.by_ket.get((wr, b), [])
+                        for bp in bps:
+                            for cp in split(bp, sp):
+                                if (c, wl, cp) not in ypanel or (cp, sp, bp) not in lay.blocks:
+                                    continue
+                                cf = coef_right(cp[1], kl, c[1], SITE_MULT[sp][1], SITE_MULT[s_][1], kop, bp[1], kr, b[1])
+                                alpha = cf * r * coef
+                                if alpha == 0.0:
+                                    continue
+                                d = segs[b1_key[(c, wl, cp, sp, bp)]]
+                                k = (_KIND_C, bi, 0) if wr == nfin_r else (_KIND_R, bi, eidx[(b, wr, bp)])
+                                d[k] = d.get(k, 0.0) + alpha
+        sym.out_has = np.array(out_has, dtype=bool)
+        sym.out_mat = np.array(out_mat, dtype=np.int64)
+        sym.zq = np.array(zq, dtype=np.int64)
+        sym.b1_panel = np.array(b1_panel, dtype=np.int64)
+        sym.b1_lb = np.array(b1_lb, dtype=np.int64)
+        sym.s1 = ApplySym._flatten(segs, len(segs))
+        return sym
+
+    def instantiate(self, Eold, lay, Enew):
+        """-> (t1, t2, z_size), identical to plan_left_env / plan_right_env"""
+        left = self.side == "L"
+        EN = np.array(list(Enew.blocks.values()) or [(0, 1, 0)], dtype=np.int64).reshape(-1, 3)      # off, m, n
+        EO = np.array(list(Eold.blocks.values()) or [(0, 1, 0)], dtype=np.int64).reshape(-1, 3)
+        LB = np.array(list(lay.blocks.values()) or [(0, 1, 1, 1)], dtype=np.int64).reshape(-1, 4)    # off, m, n, ld
+        MT = np.array([v[:3] for v in lay.mats.values()] or [(0, 1, 1)], dtype=np.int64).reshape(-1, 3)   # off, rows, cols
+        nq = len(Enew.blocks)
+        zq = self.zq
+        npan = len(zq)
+        pm = MT[self.out_mat[zq]] if npan else np.zeros((0, 3), dtype=np.int64)
+        if left:           # panel: rows_cp x n(new block)
+            zrows, zcols = pm[:, 1], EN[zq, 2]
+        else:              # panel: m(new block) x cols_cp
+            zrows, zcols = EN[zq, 1], pm[:, 2]
+        zsz = zrows * zcols
+        zoff = np.cumsum(zsz) - zsz
+        zsize = int(zsz.sum())
+        # ---- stage 2: one GEMM per new block that has a panel ----
+        s2 = np.zeros(max(npan, 1), dtype=SEG_DT)
+        B2 = np.zeros((nq, 9), dtype=np.int64)
+        B2[:, 0], B2[:, 1], B2[:, 2], B2[:, 3], B2[:, 4] = EN[:nq, 0], BUF_Y, EN[:nq, 1], EN[:nq, 1], EN[:nq, 2]
+        if npan:
+            s2["type"], s2["alpha_re"] = SEG_GEMM, 1.0
+            if left:       # new = A_cp^H . Y
+                s2["buf_a"], s2["a_off"], s2["lda"], s2["op_a"] = BUF_S1, pm[:, 0], pm[:, 1], OP_C
+                s2["buf_b"], s2["b_off"], s2["ldb"], s2["op_b"] = BUF_Z, zoff, pm[:, 1], OP_N
+                s2["k"] = pm[:, 1]
+            else:          # new = Y . B_cp^H
+                s2["buf_a"], s2["a_off"], s2["lda"], s2["op_a"] = BUF_Z, zoff, EN[zq, 1], OP_N
+                s2["buf_b"], s2["b_off"], s2["ldb"], s2["op_b"] = BUF_S1, pm[:, 0], pm[:, 1], OP_C
+                s2["k"] = pm[:, 2]
+            has_pos = np.cumsum(self.out_has) - 1
+            B2[:, 5] = np.where(self.out_has, has_pos, npan)        # blocks without a panel: empty segment range
+            B2[:, 6] = self.out_has.astype(np.int64)
+            B2[:, 8] = np.where(self.out_has, s2["k"][np.clip(has_pos, 0, npan - 1)], 0)
+            # TaskList.finalize numbers seg_begin by running position: a block without segments gets the position
+            # of the next segment
+            B2[:, 5] = np.cumsum(np.concatenate([[0], B2[:-1, 6]]))
+        f2 = int(8 * (B2[:, 3] * B2[:, 4] * B2[:, 8]).sum())
+        t2 = _emit_tasks(s2, npan > 0, B2, npan, f2) if nq else Tasks(np.zeros(1, dtype=TILE_DT), 0, s2, 0, 0)
+        # ---- stage 1: panel sub-blocks ----
+        nb1 = len(self.b1_panel)
+        pan, lb = self.b1_panel, self.b1_lb
+        B1 = np.zeros((nb1, 9), dtype=np.int64)
+        if nb1:
+            pmat = MT[self.out_mat[zq[pan]]]
+            if left:       # rows of group (ap, sp) inside the panel
+                B1[:, 0] = zoff[pan] + (LB[lb, 0] - pmat[:, 0])
+                B1[:, 2], B1[:, 3], B1[:, 4] = pmat[:, 1], LB[lb, 1], zcols[pan]
+            else:          # columns of group (sp, bp): offset co * m
+                co = (LB[lb, 0] - pmat[:, 0]) // np.maximum(pmat[:, 1], 1)
+                B1[:, 0] = zoff[pan] + co * zrows[pan]
+                B1[:, 2], B1[:, 3], B1[:, 4] = zrows[pan], zrows[pan], LB[lb, 2]
+            B1[:, 1] = BUF_Z
+        blk, kind, i1, i2, al, begin, count, ncopy = self.s1
+        n1 = len(blk)
+        s1 = np.zeros(max(n1, 1), dtype=SEG_DT)
+        ksum = np.zeros(nb1, dtype=np.int64)
+        if n1:
+            isC, isL, isR = kind == _KIND_C, kind == _KIND_L, kind == _KIND_R
+            iE = np.where(isL, i1, np.where(isR, i2, 0))
+            iS = np.where(isL, i2, i1)                       # the site block
+            s1["type"] = np.where(isC, SEG_COPY, SEG_GEMM)
+            s1["alpha_re"], s1["alpha_im"] = al.real, al.imag
+            s1["op_a"], s1["op_b"] = OP_N, OP_N
+            # COPY: B = site block.  L: A = env (lo, lm), B = site.  R: A = site, B = env (ro, rm), k = rm
+            s1["buf_a"] = np.where(isL, BUF_L, np.where(isR, BUF_S1, 0))
+            s1["a_off"] = np.where(isL, EO[iE, 0], np.where(isR, LB[iS, 0], 0))
+            s1["lda"] = np.where(isL, EO[iE, 1], np.where(isR, LB[iS, 3], 1))
+            s1["buf_b"] = np.where(isR, BUF_R, BUF_S1)
+            s1["b_off"] = np.where(isR, EO[iE, 0], LB[iS, 0])
+            s1["ldb"] = np.where(isR, EO[iE, 1], LB[iS, 3])
+            s1["k"] = np.where(isL, EO[iE, 2], np.where(isR, EO[iE, 1], 0))
+            ksum = np.bincount(blk, weights=np.where(isC, 0, s1["k"]), minlength=nb1).astype(np.int64)
+        B1[:, 5], B1[:, 6], B1[:, 7], B1[:, 8] = begin, count, ncopy, ksum
+        f1 = int(8 * (B1[:, 3] * B1[:, 4] * B1[:, 8]).sum())
+        t1 = _emit_tasks(s1, n1 > 0, B1, n1, f1) if nb1 else Tasks(np.zeros(1, dtype=TILE_DT), 0, s1, n1, 0)
+        return t1, t2, zsize
+
+
+_ENV_SYM = {}
+
+
+def plan_env_cached(side, Eold: EnvLayout, lay: SiteLayout, W, Enew: EnvLayout):
+    """plan_left_env / plan_right_env through the symbolic cache"""
+    key = (side, tuple(lay.bond_l.secs), tuple(lay.bond_r.secs), _wkey(W))
+    sym = _ENV_SYM.get(key)
+    if sym is None:
+        if len(_ENV_SYM) > 4000:
+            _ENV_SYM.clear()
+        sym = _ENV_SYM[key] = EnvSym.build(side, Eold, lay, W, Enew)
+    return sym.instantiate(Eold, lay, Enew)
+
+
 # ----------------------------------------------------------------------------------------------
 # SVD staging / truncation
 # ----------------------------------------------------------------------------------------------

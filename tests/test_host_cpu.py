@@ -299,3 +299,39 @@ def test_vectorised_finalize_plan_equals_general_path():
             assert a.dtype == b.dtype and np.array_equal(a, b)
         assert ref[4].tiles.tobytes() == new[4].tiles.tobytes() and ref[4].segs.tobytes() == new[4].segs.tobytes()
         assert ref[4].flops == new[4].flops
+
+
+def test_symbolic_environment_plans_equal_loop_plans():
+    """plan_env_cached (index structure cached by sector sets, instantiated by numpy gathers) == plan_left_env /
+    plan_right_env byte for byte: every bond of a short chain (ends included) and perturbed bulk tables"""
+    from hubbardtn_amd import models, mps, planner as pl
+    rng = np.random.default_rng(5)
+
+    def same(a, b):
+        return (a.ntiles == b.ntiles and a.nsegs == b.nsegs and a.flops == b.flops
+                and a.tiles[:a.ntiles].tobytes() == b.tiles[:b.ntiles].tobytes()
+                and a.segs[:a.nsegs].tobytes() == b.segs[:b.nsegs].tobytes())
+
+    def check(b0, b1, W):
+        layL, layR = pl.SiteLayout.build("L", b0, b1), pl.SiteLayout.build("R", b0, b1)
+        Ll, Lnew = pl.EnvLayout.build("L", b0, W.left), pl.EnvLayout.build("L", b1, W.right)
+        Rl, Rnew = pl.EnvLayout.build("R", b1, W.right), pl.EnvLayout.build("R", b0, W.left)
+        ref, new = pl.plan_left_env(Ll, layL, W, Lnew), pl.plan_env_cached("L", Ll, layL, W, Lnew)
+        assert same(ref[0], new[0]) and same(ref[1], new[1]) and ref[2] == new[2]
+        ref, new = pl.plan_right_env(Rl, layR, W, Rnew), pl.plan_env_cached("R", Rl, layR, W, Rnew)
+        assert same(ref[0], new[0]) and same(ref[1], new[1]) and ref[2] == new[2]
+    L = 8
+    for tt, uu in (([1.0], [4.0]), ([1.0, 0.3], [4.0, 0.5])):
+        mpo = models.hamiltonian(models.OB_Sim(tt, uu), L)
+        bonds = [pl.Bond(b) for b in mps.random_mps(L, (L, 0), 5, seed=2)[0]]
+        for i in range(L):
+            check(bonds[i], bonds[i + 1], mpo[i])
+    tab = {(2, 0): 2, (2, 2): 1, (3, 1): 6, (3, 3): 3, (4, 0): 9, (4, 2): 8, (4, 4): 2, (5, 1): 11, (5, 3): 6, (6, 0): 7,
+           (6, 2): 9, (6, 4): 3, (7, 1): 5, (7, 3): 2, (8, 0): 2}
+    mpo = models.hamiltonian(models.OB_Sim([1.0, 0.1], [4.0]), 24)
+    base0 = {(N + 8, j): n for (N, j), n in tab.items()}
+    keys1 = sorted({b for c in base0 for s in range(3) for b in pl.fuse(c, s) if b[1] <= 4})
+    base1 = {k: int(rng.integers(2, 12)) for k in keys1}
+    for trial in range(3):                      # same sector sets, different multiplicities: the cached structure is reused
+        pert = lambda n: max(1, int(n + rng.integers(-2, 3)))
+        check(pl.Bond({k: pert(v) for k, v in base0.items()}), pl.Bond({k: pert(v) for k, v in base1.items()}), mpo[11])
