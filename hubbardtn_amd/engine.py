@@ -264,14 +264,25 @@ class DMRG2:
         info_h = ops.to_host(info)
         if nb and int(info_h[:nb].min()) < 0:
             raise RuntimeError("Jacobi SVD did not converge")
-        svals, order = {}, {}
-        for k, c in enumerate(sp.mids):
-            so, nn = int(sp.desc[k]["s_off"]), int(sp.desc[k]["n"])
-            s = s_host[so:so + nn]
-            p = np.argsort(-s, kind="stable")
-            order[c] = p
-            svals[c] = s[p]
-        keep, tw, nrm = pl.truncate(svals, self.chi_full, self.cutoff, self.weighting)
+        # per-block descending order and the global truncation on flat arrays (one lexsort instead of a Python loop
+        # over the blocks; the sector numbering of sp.mids is the sorted label order truncate() uses)
+        st_ = sp.__dict__.get("_flat")
+        if st_ is None:
+            offs = sp.desc["s_off"][:nb].astype(np.int64)
+            lens = sp.desc["n"][:nb].astype(np.int64)
+            assert list(sp.mids) == sorted(sp.mids) and np.array_equal(offs, np.cumsum(lens) - lens)
+            sid = np.repeat(np.arange(nb), lens)
+            st_ = sp.__dict__["_flat"] = (offs, lens, sid, np.arange(int(lens.sum())) - np.repeat(offs, lens),
+                                          np.array([c[1] + 1 for c in sp.mids], dtype=np.int64)[sid])
+        offs, lens, sid, pos, dims = st_
+        sv = s_host[:len(sid)]
+        perm = np.lexsort((pos, -sv, sid))                    # by block, value descending, original index ascending
+        vals = sv[perm]
+        counts, tw, nrm = pl.truncate_arrays(vals, sid, pos, dims, nb, self.chi_full, self.cutoff, self.weighting)
+        local = perm - np.repeat(offs, lens)                  # column index inside its block
+        svals = {c: vals[offs[k]:offs[k] + lens[k]] for k, c in enumerate(sp.mids)}
+        order = {c: local[offs[k]:offs[k] + lens[k]] for k, c in enumerate(sp.mids)}
+        keep = {c: int(counts[k]) for k, c in enumerate(sp.mids)}
         mid = Bond({c: k for c, k in keep.items() if k > 0})
         layA = self._site_layout("L", bl, mid)
         layB = self._site_layout("R", mid, br)

@@ -1047,6 +1047,14 @@ def truncate(svals: dict, chi_full=None, cutoff=0.0, weighting="sqrtdim", rel_fl
     sid = np.repeat(np.arange(len(secs)), lens)
     idx = np.concatenate([np.arange(n) for n in lens]) if len(vals) else np.zeros(0, dtype=int)
     dims = np.array([c[1] + 1 for c in secs], dtype=np.int64)[sid]
+    counts, tw, nrm = truncate_arrays(vals, sid, idx, dims, len(secs), chi_full, cutoff, weighting, rel_floor)
+    return {c: int(counts[i]) for i, c in enumerate(secs)}, tw, nrm
+
+
+def truncate_arrays(vals, sid, idx, dims, nsec, chi_full=None, cutoff=0.0, weighting="sqrtdim", rel_floor=1e-14):
+    """truncate() on flat arrays: vals sorted descending inside every sector, sid = sector number (sectors numbered
+    in sorted label order), idx = position inside the sector, dims = 2S+1 per value.  -> (counts[nsec], discarded
+    weight, norm of the kept part)"""
     smax = float(vals.max()) if len(vals) else 0.0
     schmidt = vals / np.sqrt(dims)
     ok = (schmidt > cutoff) & (vals > rel_floor * smax)
@@ -1060,11 +1068,10 @@ def truncate(svals: dict, chi_full=None, cutoff=0.0, weighting="sqrtdim", rel_fl
         if len(over):
             keep_n = max(int(over[0]), 1)          # (the largest multiplet is always kept, even if wider than chi_full)
     kept = order[:keep_n]
-    counts = np.bincount(sid[kept], minlength=len(secs))
-    keep = {c: int(counts[i]) for i, c in enumerate(secs)}
+    counts = np.bincount(sid[kept], minlength=nsec)
     total = float(np.sum(vals ** 2))
     kept_w = float(np.sum(vals[kept] ** 2))
-    return keep, (total - kept_w) / total if total > 0 else 0.0, sqrt(kept_w)
+    return counts, (total - kept_w) / total if total > 0 else 0.0, sqrt(kept_w)
 
 
 def _plan_finalize_fast(tl, sp, order, keep, layA, layB, placement, offA, offB):
