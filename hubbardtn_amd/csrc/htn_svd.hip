@@ -1374,9 +1374,11 @@ __global__ __launch_bounds__(256) void k_batched_copy(double2* __restrict__ dst,
                                                       const int32_t* __restrict__ idx,
                                                       const double* __restrict__ scl,
                                                       const htn_copy_item* __restrict__ items, double gscale) {
+    // grid = (items, COPY_SPLIT): the largest item (a 200 x 250 block) would otherwise occupy ONE workgroup for
+    // ~80 us while the other CUs idle; the element range of every item is dealt over gridDim.y workgroups
     const htn_copy_item I = items[blockIdx.x];
     const int total = I.rows * I.cols;
-    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < total; e += blockDim.x * gridDim.y) {
         const int i = e % I.rows, j = e / I.rows;
         // gathered source index along gather_dim of dst
         int gi = i, gj = j;
@@ -1403,7 +1405,7 @@ extern "C" int htn_batched_copy_z(void* dst, const void* src, const int32_t* idx
                                   const htn_copy_item* items, int32_t n_items, double global_scale,
                                   void* stream) {
     if (n_items <= 0) return 0;
-    hipLaunchKernelGGL(k_batched_copy, dim3(n_items), dim3(256), 0, (hipStream_t)stream, (double2*)dst,
+    hipLaunchKernelGGL(k_batched_copy, dim3(n_items, 16), dim3(256), 0, (hipStream_t)stream, (double2*)dst,
                        (const double2*)src, idx, scl, items, global_scale);
     HIP_TRY(hipGetLastError());
     return 0;
