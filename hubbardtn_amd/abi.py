@@ -36,7 +36,7 @@ assert TILE_DT.itemsize == 48 and SEG_DT.itemsize == 64 and SVD_DT.itemsize == 4
 
 EXPORTS = ["htn_last_error", "htn_abi_version", "htn_device_init", "htn_grouped_gemm_z",
            "htn_dots_scratch_elems", "htn_dots_z", "htn_axpys_z", "htn_scale_inv_sqrt_z",
-           "htn_jacobi_svd_z", "htn_jacobi_set_split", "htn_batched_copy_z", "htn_lanczos_scratch_elems", "htn_lanczos_z"]
+           "htn_jacobi_svd_z", "htn_jacobi_set_split", "htn_jacobi_set_rank_cut", "htn_batched_copy_z", "htn_lanczos_scratch_elems", "htn_lanczos_z"]
 
 
 class GemmLaunch(C.Structure):
@@ -80,6 +80,8 @@ def load_library(path: str | None = None):
     lib.htn_jacobi_svd_z.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f64, vp, vp]
     lib.htn_jacobi_set_split.argtypes = [i32]
     lib.htn_jacobi_set_split.restype = i32
+    lib.htn_jacobi_set_rank_cut.argtypes = [f64]
+    lib.htn_jacobi_set_rank_cut.restype = f64
     lib.htn_batched_copy_z.argtypes = [vp, vp, vp, vp, vp, i32, f64, vp]
     lib.htn_lanczos_scratch_elems.argtypes = [i32]
     lib.htn_lanczos_scratch_elems.restype = i64

@@ -277,8 +277,8 @@ __device__ __forceinline__ int jacobi_dispatch_e(C g, int E, int n, int max_swee
 // back -- is exactly the isometry the caller asked for (it staged G0 = M^H or M accordingly).
 // Columns are not swapped physically: s_col[k] is the physical column of logical position k.
 template <int GS>
-__device__ __forceinline__ void qrcp_mgs(double2* __restrict__ g0, int m0, int n0, int r, const SplitCols X,
-                                         int* s_col, double* s_cn2, double* s_piv, int tid) {
+__device__ __forceinline__ int qrcp_mgs(double2* __restrict__ g0, int m0, int n0, int r, const SplitCols X,
+                                        int* s_col, double* s_cn2, double* s_piv, int tid, double cut2) {
     const int grp = tid / GS, sub = tid % GS, lane = tid & 63, wave = tid >> 6;
     const int ngroups = JAC_THREADS / GS;
     for (int idx = tid; idx < X.mp * r; idx += JAC_THREADS) X.col(idx / X.mp)[idx % X.mp] = make_double2(0.0, 0.0);
@@ -303,15 +303,19 @@ __device__ __forceinline__ void qrcp_mgs(double2* __restrict__ g0, int m0, int n
     }
     __syncthreads();
     const double zero2 = s_piv[1];
+    int rank = 0;
     for (int j = 0; j < r; ++j) {
         if (wave == 0) {                            // pivot = remaining column of largest norm
-            double best = -1.0;
+            double best = -1.0, mass = 0.0;
             int bi = j;
-            for (int k = j + lane; k < n0; k += 64)
+            for (int k = j + lane; k < n0; k += 64) {
+                mass += s_cn2[k];                   // |R22|_F^2: bounds every remaining singular value (rank cut)
                 if (s_cn2[k] > best) {
                     best = s_cn2[k];
                     bi = k;
                 }
+            }
+            mass = wave_sum(mass);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 const double ob = __shfl_xor(best, off, 64);
@@ -334,11 +338,12 @@ __device__ __forceinline__ void qrcp_mgs(double2* __restrict__ g0, int m0, int n
                 s_col[bi] = t;
                 s_cn2[bi] = s_cn2[j];
                 s_cn2[j] = best;
-                s_piv[0] = best;
+                s_piv[0] = mass <= cut2 ? 0.0 : best;
             }
         }
         __syncthreads();
         if (s_piv[0] <= zero2) break;               // numerically rank deficient: remaining R rows are zero
+        rank = j + 1;
         const double2* __restrict__ p = g0 + (int64_t)s_col[j] * m0;
         for (int k = j + grp; k < n0; k += ngroups) {
             // every group recomputes |p|^2 itself (bitwise identical everywhere): no normalisation pass
@@ -387,6 +392,7 @@ __device__ __forceinline__ void qrcp_mgs(double2* __restrict__ g0, int m0, int n
         __syncthreads();
     }
     __syncthreads();
+    return rank;
 }
 
 // workgroup barrier that orders LDS traffic only (__syncthreads() also drains the vector-memory queue; the
@@ -410,9 +416,9 @@ __device__ __forceinline__ void lds_barrier() {
 // R factor is backward stable like that of column MGS.  R entries are stored by PHYSICAL column index
 // (X[j][phys k] = conj(r_jk)), so nothing is ever swapped and the row permutation handed on is the identity.
 template <int EL>
-__device__ __forceinline__ void qrcp_blocked(double2* __restrict__ g0, int m0, int n0, int r,
-                                             double2* __restrict__ Xg, int mp, int* s_col, double* s_cn2,
-                                             double* s_piv, double2* Qn, int tid) {
+__device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, int n0, int r,
+                                            double2* __restrict__ Xg, int mp, int* s_col, double* s_cn2,
+                                            double* s_piv, double2* Qn, int tid, double cut2) {
     __shared__ double s_pn[16];
     __shared__ double2 s_r[16][17];      // the panel's own R block, [pivot step][owner wave]; flushed once per panel
     __shared__ int s_pc[16];
@@ -443,13 +449,19 @@ __device__ __forceinline__ void qrcp_blocked(double2* __restrict__ g0, int m0, i
     __syncthreads();
     const double zero2 = s_piv[1];
     bool stop = false;
-    int j0 = 0;
+    int j0 = 0, rank = 0;
     while (j0 < r && !stop) {
         const int nbmax = r - j0 < 16 ? r - j0 : 16;
         // ---- (a) window: the nbmax largest remaining columns move to logical positions j0 .. ----
         if (wave == 0) {
             int nb = 0;
-            for (int t = 0; t < nbmax; ++t) {
+            // rank-revealing stop: the squared Frobenius norm of everything not yet factorised (= |R22|_F^2, the
+            // residual column norms are recomputed exactly) bounds every remaining singular value; below the
+            // caller's cut (htn_jacobi_set_rank_cut) the remaining rows of R are dropped
+            double mass = 0.0;
+            for (int k = j0 + lane; k < n0; k += 64) mass += s_cn2[k];
+            mass = wave_sum(mass);
+            for (int t = 0; t < (mass <= cut2 ? 0 : nbmax); ++t) {
                 const int j = j0 + t;
                 // key = norm bits with the low 10 mantissa bits replaced by 1023 - k: one 64-bit max finds the
                 // largest norm, ties (to 2^-42 relative) going to the smallest position
@@ -670,10 +682,12 @@ __device__ __forceinline__ void qrcp_blocked(double2* __restrict__ g0, int m0, i
         }
         __syncthreads();
         j0 += nb;
+        rank += nb_eff;
     }
     __syncthreads();
     for (int i = tid; i < n0; i += JAC_THREADS) s_col[i] = i;      // rows of X are physical columns already
     __syncthreads();
+    return rank;
 }
 
 // one workgroup per LARGE block (X = R^H does not fit the LDS window): pivoted QR only; the sweeps follow as
@@ -681,7 +695,8 @@ __device__ __forceinline__ void qrcp_blocked(double2* __restrict__ g0, int m0, i
 __global__ __launch_bounds__(JAC_THREADS) void k_qr_large(double2* __restrict__ G, double2* __restrict__ Vj,
                                                           const htn_svd_block* __restrict__ desc,
                                                           const int* __restrict__ large_ids, int* __restrict__ perm,
-                                                          double* __restrict__ zero2_out) {
+                                                          double* __restrict__ zero2_out, double cut2,
+                                                          int* __restrict__ rank_host) {
     extern __shared__ double2 g_lds[];
     __shared__ double s_piv[2];
     __shared__ int s_col[64 * JAC_MAXEL];
@@ -691,8 +706,13 @@ __global__ __launch_bounds__(JAC_THREADS) void k_qr_large(double2* __restrict__ 
     const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
     const int mp = gsx * ((m + gsx - 1) / gsx);
     double2* __restrict__ X = Vj + D.v_off;
-    if (m0 <= 256) qrcp_blocked<4>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid);
-    else qrcp_blocked<8>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid);
+    int rank;
+    if (m0 <= 256) rank = qrcp_blocked<4>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2);
+    else rank = qrcp_blocked<8>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2);
+    if (tid == 0) {
+        rank_host[blockIdx.x] = rank;               // host-pinned: the host sizes the Jacobi tournament with it
+        __threadfence_system();
+    }
     // |X|_F^2 -> threshold for "numerically zero" columns (fixed-order sums: bit-reproducible)
     double f = 0.0;
     for (int idx = tid; idx < mp * n; idx += JAC_THREADS) {
@@ -714,7 +734,8 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
                                                             double* __restrict__ S,
                                                             const htn_svd_block* __restrict__ desc,
                                                             int max_sweeps, double tol, int* __restrict__ info,
-                                                            int lds_elems, const int* __restrict__ large_slot) {
+                                                            int lds_elems, const int* __restrict__ large_slot,
+                                                            double cut2) {
     extern __shared__ double2 g_lds[];
     __shared__ double s_ratio;
     __shared__ double s_piv[2];
@@ -743,9 +764,10 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
         const bool x_lds = (int64_t)mp * n <= lds_elems;
         const int nl = x_lds ? n : 0;
         const SplitCols X = {(double2*)g_lds, v, nl, mp};
-        if (m0 <= 16 * JAC_MAXEL) qrcp_mgs<16>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid);
-        else if (m0 <= 32 * JAC_MAXEL) qrcp_mgs<32>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid);
-        else qrcp_mgs<64>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid);
+        int rank;                 // columns of X the sweeps have to visit (the others are zero)
+        if (m0 <= 16 * JAC_MAXEL) rank = qrcp_mgs<16>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid, cut2);
+        else if (m0 <= 32 * JAC_MAXEL) rank = qrcp_mgs<32>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid, cut2);
+        else rank = qrcp_mgs<64>(gglob, m0, m, n, X, s_col, s_cn2, s_piv, tid, cut2);
         {   // |X|_F^2 -> threshold for "numerically zero" columns
             double f = 0.0;
             for (int idx = tid; idx < mp * n; idx += JAC_THREADS) {
@@ -767,14 +789,14 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict_
         int swq;
         if (x_lds) {        // everything in LDS: ds_* addressing
             const DenseCols<double2*> dc = {(double2*)g_lds, mp};
-            if (gsx == 16) swq = jacobi_dispatch_e<16>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
-            else if (gsx == 32) swq = jacobi_dispatch_e<32>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
-            else swq = jacobi_dispatch_e<64>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
+            if (gsx == 16) swq = jacobi_dispatch_e<16>(dc, E, rank, max_sweeps, tol, &s_ratio, tid, zero2q);
+            else if (gsx == 32) swq = jacobi_dispatch_e<32>(dc, E, rank, max_sweeps, tol, &s_ratio, tid, zero2q);
+            else swq = jacobi_dispatch_e<64>(dc, E, rank, max_sweeps, tol, &s_ratio, tid, zero2q);
         } else {            // everything in global memory (L2 resident): global_* addressing
             const DenseCols<double2*> dc = {v, mp};
-            if (gsx == 16) swq = jacobi_dispatch_e<16>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
-            else if (gsx == 32) swq = jacobi_dispatch_e<32>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
-            else swq = jacobi_dispatch_e<64>(dc, E, n, max_sweeps, tol, &s_ratio, tid, zero2q);
+            if (gsx == 16) swq = jacobi_dispatch_e<16>(dc, E, rank, max_sweeps, tol, &s_ratio, tid, zero2q);
+            else if (gsx == 32) swq = jacobi_dispatch_e<32>(dc, E, rank, max_sweeps, tol, &s_ratio, tid, zero2q);
+            else swq = jacobi_dispatch_e<64>(dc, E, rank, max_sweeps, tol, &s_ratio, tid, zero2q);
         }
         __syncthreads();
         // column norms + write back with the pivoting undone: row k of X is row s_col[k] of the result
@@ -1207,6 +1229,16 @@ static int js_reserve(size_t dev_bytes, size_t pin_bytes) {
 // elements of R^H above which a QRCP block leaves the one-workgroup kernel for the multi-kernel path; the default
 // (0) is "does not fit the LDS window".  Lower values exist to exercise the large-block path on small problems.
 static int g_jac_split = 0;
+// absolute cut of the rank-revealing QR of the large blocks (0 = off): directions whose singular values are all below
+// it (squared Frobenius mass of the unfactorised part <= cut^2) are dropped before the Jacobi sweeps; their singular
+// values are reported as 0.  The caller chooses it from what it is going to truncate anyway.
+static double g_jac_cut = 0.0;
+extern "C" double htn_jacobi_set_rank_cut(double abs_cut) {
+    const double prev = g_jac_cut;
+    g_jac_cut = abs_cut > 0.0 ? abs_cut : 0.0;
+    return prev;
+}
+
 extern "C" int32_t htn_jacobi_set_split(int32_t elems) {
     const int32_t prev = g_jac_split;
     g_jac_split = elems > 0 ? elems : 0;
@@ -1244,54 +1276,62 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         }
     if (large.empty()) {
         hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2), st, (double2*)G,
-                           (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)nullptr);
+                           (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)nullptr,
+                           g_jac_cut * g_jac_cut);
         HIP_TRY(hipGetLastError());
         return 0;
     }
 
     const int nl = (int)large.size();
-    // panel-pair work lists, one per round of the round-robin tournament over the column panels of each block
+    // panel-pair work lists, one per round of the round-robin tournament over the column panels of each block;
+    // built AFTER the QR has been enqueued (and, with a rank cut, after it has reported the ranks)
     std::vector<std::vector<JacPairItem>> rounds;
     std::vector<JacPairItem> intra;
     int max_mp = 0;
+    size_t n_items_max = 0;
     for (int li = 0; li < nl; ++li) {
         const htn_svd_block& D = desc_host[large[li]];
         const int gsx = D.m <= 16 * JAC_MAXEL ? 16 : (D.m <= 32 * JAC_MAXEL ? 32 : 64);
-        const int mp = gsx * ((D.m + gsx - 1) / gsx);
-        max_mp = std::max(max_mp, mp);
-        const int w = JAC_PANEL;
-        const int nb = (D.n + w - 1) / w;
-        const int nbp = nb + (nb & 1);
-        if ((int)rounds.size() < nbp - 1) rounds.resize(nbp - 1);
-        for (int r = 0; r < nbp - 1; ++r)
-            for (int p = 0; p < nbp / 2; ++p) {
-                int a = p == 0 ? nbp - 1 : (r + p) % (nbp - 1);
-                int c = p == 0 ? r : (r + nbp - 1 - p) % (nbp - 1);
-                if (a >= nb || c >= nb) continue;
-                if (a > c) std::swap(a, c);
-                JacPairItem it = {li, a * w, std::min(w, D.n - a * w), c * w, std::min(w, D.n - c * w), {0, 0, 0}};
-                rounds[r].push_back(it);
-            }
-        // the pairs inside each panel, two panels per workgroup, once per outer sweep
-        for (int a = 0; a < nb; a += 2) {
-            const int c = a + 1;
-            JacPairItem it = {li, a * w, std::min(w, D.n - a * w), c < nb ? c * w : 0,
-                              c < nb ? std::min(w, D.n - c * w) : 0, {1, 0, 0}};
-            intra.push_back(it);
-        }
+        max_mp = std::max(max_mp, gsx * ((D.m + gsx - 1) / gsx));
+        const int nb = (D.n + JAC_PANEL - 1) / JAC_PANEL, nbp = nb + (nb & 1);
+        n_items_max += (size_t)(nbp - 1) * (nbp / 2) + (nb + 1) / 2;
     }
-    // the intra-panel visit closes the sweep: one outer sweep fewer than with it in front (measured on graded
-    // spectra and in the DMRG sweep; the cross visits leave the panels' own pairs slightly non-orthogonal)
-    rounds.push_back(intra);
-    size_t n_items = 0;
-    for (auto& r : rounds) n_items += r.size();
+    auto build_rounds = [&](const int* n_eff) {
+        const int w = JAC_PANEL;
+        for (int li = 0; li < nl; ++li) {
+            const int n = n_eff[li];
+            if (n < 1) continue;
+            const int nb = (n + w - 1) / w;
+            const int nbp = nb + (nb & 1);
+            if ((int)rounds.size() < nbp - 1) rounds.resize(nbp - 1);
+            for (int r = 0; r < nbp - 1; ++r)
+                for (int p = 0; p < nbp / 2; ++p) {
+                    int a = p == 0 ? nbp - 1 : (r + p) % (nbp - 1);
+                    int c = p == 0 ? r : (r + nbp - 1 - p) % (nbp - 1);
+                    if (a >= nb || c >= nb) continue;
+                    if (a > c) std::swap(a, c);
+                    JacPairItem it = {li, a * w, std::min(w, n - a * w), c * w, std::min(w, n - c * w), {0, 0, 0}};
+                    rounds[r].push_back(it);
+                }
+            // the pairs inside each panel, two panels per workgroup, once per outer sweep
+            for (int a = 0; a < nb; a += 2) {
+                const int c = a + 1;
+                JacPairItem it = {li, a * w, std::min(w, n - a * w), c < nb ? c * w : 0,
+                                  c < nb ? std::min(w, n - c * w) : 0, {1, 0, 0}};
+                intra.push_back(it);
+            }
+        }
+        // the intra-panel visit closes the sweep: one outer sweep fewer than with it in front (measured on graded
+        // spectra and in the DMRG sweep; the cross visits leave the panels' own pairs slightly non-orthogonal)
+        rounds.push_back(intra);
+    };
     // device scratch layout: [large_ids | slot of every block | perm | zero2 | ratio | done | sweeps | items]
     const size_t off_ids = 0, off_slot = off_ids + sizeof(int) * nl, off_perm = off_slot + sizeof(int) * n_blocks;
     const size_t off_zero = off_perm + sizeof(int) * nl * 64 * JAC_MAXEL;
     const size_t off_ratio = (off_zero + sizeof(double) * nl + 7) / 8 * 8, off_done = off_ratio + 8 * nl;
     const size_t off_sw = off_done + sizeof(int) * nl, off_items = (off_sw + sizeof(int) * nl + 31) / 32 * 32;
-    const size_t dev_bytes = off_items + sizeof(JacPairItem) * n_items;
-    if (js_reserve(dev_bytes, sizeof(JacPairItem) * n_items + 16 * nl + 4 * n_blocks + 4 * (size_t)(max_sweeps + 1) + 128))
+    const size_t dev_bytes = off_items + sizeof(JacPairItem) * n_items_max;
+    if (js_reserve(dev_bytes, sizeof(JacPairItem) * n_items_max + 24 * nl + 4 * n_blocks + 4 * (size_t)(max_sweeps + 1) + 128))
         return 1;
     char* d = (char*)g_js.dev;
     int* d_ids = (int*)(d + off_ids);
@@ -1302,25 +1342,18 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     int* d_done = (int*)(d + off_done);
     int* d_sw = (int*)(d + off_sw);
     JacPairItem* d_items = (JacPairItem*)(d + off_items);
-    // pinned staging: [items | ids | slot of every block | active count per sweep (written by the device)]
+    // pinned staging: [items | ids | slot of every block | active count per sweep | rank per large block]
+    // (the last two are written by the device)
     char* h = (char*)g_js.pinned;
     JacPairItem* h_items = (JacPairItem*)h;
-    int* h_ids = (int*)(h + sizeof(JacPairItem) * n_items);
+    int* h_ids = (int*)(h + sizeof(JacPairItem) * n_items_max);
     int* h_slot = (int*)((char*)h_ids + 16 * ((nl * 4 + 15) / 16));
     volatile int* h_active = (volatile int*)(h_slot + n_blocks);
+    volatile int* h_rank = h_active + (max_sweeps + 1);
     for (int b = 0; b < n_blocks; ++b) h_slot[b] = -1;
     for (int li = 0; li < nl; ++li) h_slot[large[li]] = li;
-    std::vector<size_t> r_off(rounds.size());
-    {
-        size_t pos = 0;
-        for (size_t r = 0; r < rounds.size(); ++r) {
-            r_off[r] = pos;
-            for (auto& it : rounds[r]) h_items[pos++] = it;
-        }
-    }
     for (int li = 0; li < nl; ++li) h_ids[li] = large[li];
     for (int k = 0; k <= max_sweeps; ++k) h_active[k] = 1;
-    HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(JacPairItem) * n_items, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_ids, h_ids, sizeof(int) * nl, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_slot, h_slot, sizeof(int) * n_blocks, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_done, 0, sizeof(int) * nl, st));
@@ -1329,15 +1362,36 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     HIP_TRY(hipEventRecord(g_js.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(g_js.aux, g_js.ev_fork, 0));
     hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2), g_js.aux,
-                       (double2*)G, (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)d_slot);
+                       (double2*)G, (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)d_slot,
+                       g_jac_cut * g_jac_cut);
     HIP_TRY(hipEventRecord(g_js.ev_join, g_js.aux));
+    const double cut2 = g_jac_cut * g_jac_cut;
     {
         int max_m0 = 0;
         for (int li = 0; li < nl; ++li) max_m0 = std::max(max_m0, (int)desc_host[large[li]].pad);
         const size_t qr_lds = (size_t)16 * (((max_m0 + 15) & ~15) + 1) * sizeof(double2);
         hipLaunchKernelGGL(k_qr_large, dim3(nl), dim3(JAC_THREADS), qr_lds, st, (double2*)G, (double2*)Vj, desc, d_ids,
-                           d_perm, d_zero);
+                           d_perm, d_zero, cut2, (int*)h_rank);
     }
+    std::vector<int> n_eff(nl);
+    for (int li = 0; li < nl; ++li) n_eff[li] = desc_host[large[li]].n;
+    if (cut2 > 0.0) {        // the tournament is sized by the ranks the QR found: wait for them (one sync per call)
+        HIP_TRY(hipEventRecord(g_js.ev_sweep[0], st));
+        HIP_TRY(hipEventSynchronize(g_js.ev_sweep[0]));
+        for (int li = 0; li < nl; ++li) n_eff[li] = std::min(n_eff[li], (int)h_rank[li]);
+    }
+    build_rounds(n_eff.data());
+    size_t n_items = 0;
+    for (auto& r : rounds) n_items += r.size();
+    std::vector<size_t> r_off(rounds.size());
+    {
+        size_t pos = 0;
+        for (size_t r = 0; r < rounds.size(); ++r) {
+            r_off[r] = pos;
+            for (auto& it : rounds[r]) h_items[pos++] = it;
+        }
+    }
+    if (n_items) HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(JacPairItem) * n_items, hipMemcpyHostToDevice, st));
     const size_t gram_lds_bytes = (size_t)(16 * (max_mp + 1) + 4 * 16 * JG_LD) * sizeof(double2);
     // sweeps are enqueued one ahead of the host's knowledge (depth-1 pipeline, like htn_lanczos_z): the device
     // decides convergence itself (k_jacobi_check), the host only learns when to stop enqueuing

@@ -185,6 +185,10 @@ class HipOps:
         """threshold (elements of R^H) above which a block takes the large-block SVD path; returns the previous one"""
         return int(self.lib.htn_jacobi_set_split(int(elems)))
 
+    def jacobi_set_rank_cut(self, abs_cut: float) -> float:
+        """absolute singular-value cut of the large blocks' rank-revealing QR (0 = off); returns the previous one"""
+        return float(self.lib.htn_jacobi_set_rank_cut(float(abs_cut)))
+
     def batched_copy(self, dst, src, idx, scl, items_dev, nitems, gscale):
         if nitems == 0:
             return

@@ -67,6 +67,14 @@ class DMRG2:
         self.jacobi_tol, self.jacobi_max_sweeps = jacobi_tol, jacobi_max_sweeps
         self.shard = shard
         self.profile = False
+        # Optional rank-revealing cut of the blocks' pivoted QR (htn_jacobi_set_rank_cut): singular directions below
+        # rank_cut x (the smallest value the last update of the same bond kept, or the truncbelow cut) are dropped
+        # before the Jacobi sweeps.  Kept singular values then move by at most cut^2 / (2 sigma), i.e. up to
+        # rank_cut^2 / 2 RELATIVE for the smallest kept one.  OFF by default: the north-star parity is 1e-8 relative
+        # on every kept Schmidt value.  Measured at chi = 1024 (energy unchanged to 3e-15 in all cases):
+        #   rank_cut 1e-3: sweep -4 %, smallest kept values to <= 5e-7 relative;  0.05: sweep -16 %, <= 1.3e-3.
+        self.rank_cut = 0.0
+        self._cut_hint = {}
         self.bonds = [Bond(b) for b in bonds]
         self._plan_cache = {}
         self.cache_hits = self.cache_misses = 0
@@ -259,7 +267,24 @@ class DMRG2:
         S = ops.empty_f64(max(sp.s_size, 1))
         info = ops.empty_i32(max(nb, 1))
         ops.batched_copy(G, x, None, None, d_stage, nb, 1.0)
-        ops.jacobi_svd(G, Vj, S, d_desc, nb, sp.max_m, self.jacobi_max_sweeps, self.jacobi_tol, info, desc_host=sp.desc)
+        # Singular directions far below what the truncation keeps need not be resolved.  truncbelow(eta): everything
+        # below eta goes anyway.  truncdim(D): if the previous update of this bond (same D) was limited by D, its
+        # smallest kept value is where the cut will fall again.  x is normalised, so values compare across sweeps.
+        cut = 0.0
+        set_cut = getattr(ops, "jacobi_set_rank_cut", None)
+        if set_cut is not None and self.rank_cut > 0.0:
+            hint = self._cut_hint.get(i + 1)
+            if hint is not None and hint[0] == (self.chi_full, self.cutoff):
+                cut = self.rank_cut * hint[1]
+            cut = max(cut, self.rank_cut * self.cutoff)
+        if cut > 0.0:
+            set_cut(cut)
+        try:
+            ops.jacobi_svd(G, Vj, S, d_desc, nb, sp.max_m, self.jacobi_max_sweeps, self.jacobi_tol, info,
+                           desc_host=sp.desc)
+        finally:
+            if cut > 0.0:
+                set_cut(0.0)
         s_host = ops.to_host(S)
         info_h = ops.to_host(info)
         if nb and int(info_h[:nb].min()) < 0:
@@ -284,6 +309,14 @@ class DMRG2:
         order = {c: local[offs[k]:offs[k] + lens[k]] for k, c in enumerate(sp.mids)}
         keep = {c: int(counts[k]) for k, c in enumerate(sp.mids)}
         mid = Bond({c: k for c, k in keep.items() if k > 0})
+        # hint for the next visit of this bond: the smallest kept value, valid only if the dimension limit (not the
+        # number of available states) ended the kept set
+        kept_tot = int(counts.sum())
+        if self.chi_full is not None and tw > 0.0 and kept_tot > 0 and kept_tot < int((vals > 0.0).sum()):
+            ends = offs + np.maximum(counts, 1) - 1
+            self._cut_hint[i + 1] = ((self.chi_full, self.cutoff), float(vals[ends][counts > 0].min()))
+        else:
+            self._cut_hint.pop(i + 1, None)
         layA = self._site_layout("L", bl, mid)
         layB = self._site_layout("R", mid, br)
         offA, offB = 0, layA.size

@@ -152,6 +152,13 @@ int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc, co
  * agree to the Jacobi tolerance either way.  Process-wide, not thread safe. */
 int32_t htn_jacobi_set_split(int32_t elems);
 
+/* Rank-revealing stop of the large blocks' pivoted QR: once the squared Frobenius norm of the part not yet
+ * factorised is below abs_cut^2 (it bounds every remaining singular value), the remaining rows of R are dropped, the
+ * Jacobi tournament runs on the rank found, and the dropped singular values are reported as 0.  abs_cut <= 0 = off
+ * (default).  A caller that truncates anyway (truncdim / truncbelow) passes a small fraction of its cut: kept singular
+ * values then move by at most abs_cut^2 / (2 sigma) (interlacing).  Returns the previous setting.  Process-wide. */
+double htn_jacobi_set_rank_cut(double abs_cut);
+
 /* dst(r x c, ldd) = op(src)(.., lds) with optional per-row / per-column real scaling:
  * generic batched strided copy used to (a) stage M or M^H into the Jacobi workspace and
  * (b) write the truncated isometries U[:, keep] / V^H[keep, :] and the centre S*V^H / U*S.

@@ -236,6 +236,53 @@ def test_jacobi_svd_rank_deficient_large_blocks(hip_ops, multi):
         assert np.abs(np.linalg.norm(mats[i] @ Viso, axis=0) - s[live]).max() <= 1e-12 * ref[0]
 
 
+def test_rank_revealing_qr_cut(hip_ops):
+    """htn_jacobi_set_rank_cut: directions below the cut are dropped before the Jacobi sweeps (their singular values
+    come back as 0); the kept ones move by at most cut^2 / (2 sigma) (interlacing) and stay an isometry"""
+    rng = np.random.default_rng(21)
+    shapes = [(220, 220), (150, 190), (260, 130), (90, 90), (60, 100), (70, 40)]     # large-block path and one-CU kernel
+    cut = 1e-6
+    desc = np.zeros(len(shapes), dtype=abi.SVD_DT)
+    go = vo = so = 0
+    mats = []
+    for i, (m0, n0) in enumerate(shapes):
+        r = min(m0, n0)
+        desc[i] = (go, vo, so, n0, r, abi.SVD_QRCP, m0)
+        U, _ = np.linalg.qr(_rand_z(rng, m0 * r).reshape(m0, r))
+        W, _ = np.linalg.qr(_rand_z(rng, n0 * r).reshape(n0, r))
+        s = 10.0 ** (-12 * np.arange(r) / max(r - 1, 1))
+        mats.append((U * s) @ W.conj().T)
+        go, vo, so = go + m0 * n0, vo + ((n0 + 63) // 64 * 64) * r, so + r
+    dG = hip_ops.to_device(np.concatenate([M.T.reshape(-1) for M in mats]))
+    dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
+    prev = hip_ops.jacobi_set_rank_cut(cut)
+    try:
+        hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), 260, 40, 1e-14, info, desc_host=desc)
+    finally:
+        hip_ops.jacobi_set_rank_cut(prev)
+    Gp, S, inf = hip_ops.to_host(dG), hip_ops.to_host(dS), hip_ops.to_host(info)
+    assert inf.min() >= 0, inf
+    for i, (m0, n0) in enumerate(shapes):
+        d = desc[i]
+        r = min(m0, n0)
+        out = Gp[d["g_off"]:d["g_off"] + n0 * r].reshape(r, n0).T
+        s = np.sort(S[d["s_off"]:d["s_off"] + r])[::-1]
+        ref = np.linalg.svd(mats[i], compute_uv=False)
+        nlive = int((s > 0).sum())
+        assert nlive < r                                              # something was dropped ...
+        assert ref[nlive] <= cut * 1.0001 if nlive < r else True      # ... and only what lies below the cut
+        assert ref[max(nlive - 17, 0)] > 0.0
+        big = ref[:nlive] > 10 * cut
+        assert np.abs(s[:nlive][big] - ref[:nlive][big]).max() <= cut ** 2 / (2 * 10 * cut) + 1e-13
+        sraw = S[d["s_off"]:d["s_off"] + r]
+        live = sraw > 0
+        Viso = out[:, live] / sraw[live]
+        assert np.abs(Viso.conj().T @ Viso - np.eye(live.sum())).max() < 1e-12
+        keep = sraw > 100 * cut                                        # well above the cut: still singular pairs of G0
+        Vk = out[:, keep] / sraw[keep]
+        assert np.abs(np.linalg.norm(mats[i] @ Vk, axis=0) - sraw[keep]).max() <= 1e-8
+
+
 def test_batched_copy_matches_numpy(hip_ops):
     rng = np.random.default_rng(5)
     src = _rand_z(rng, 5000)
