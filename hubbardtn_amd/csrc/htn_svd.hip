@@ -887,13 +887,6 @@ struct JacPairItem {
 // the exact Gram of the visit.  The pivot 2 x 2 block is updated with Rutishauser's formulas
 // (a' = a - t|g|, b' = b + t|g|, 0 off-diagonal), which keep the small diagonal entries of a graded Gram
 // matrix relatively accurate (Demmel & Veselic 1992); the remaining entries use the plain bilinear update.
-struct JacRot {
-    double jjr, jji;        // J[j][j]
-    double jpr, jpi;        // J[partner(j)][j]
-    double dnew;            // new diagonal entry of column j's pivot block
-    int flag, pad;
-};
-
 // partner of LDS column slot x in round r.  mode 0 (cross visit, 8 rounds): slot p of panel A meets slot
 // 8 + (p + r) % 8 of panel B -- every A-B pair exactly once.  mode 1 (intra visit, 7 rounds): round-robin
 // tournament inside each group of 8 slots.
