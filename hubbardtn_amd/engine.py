@@ -317,21 +317,33 @@ class DMRG2:
             self._cut_hint[i + 1] = ((self.chi_full, self.cutoff), float(vals[ends][counts > 0].min()))
         else:
             self._cut_hint.pop(i + 1, None)
-        layA = self._site_layout("L", bl, mid)
-        layB = self._site_layout("R", mid, br)
+        # the finalisation plan depends on the kept COUNTS only (not on which columns carry them): in converged sweeps
+        # the same counts recur at the same bond, so layouts, copy items and the centre GEMM list (already on the
+        # device) are memoised; only the column indices travel per update
+        def build_fin():
+            layA_ = self._site_layout("L", bl, mid)
+            layB_ = self._site_layout("R", mid, br)
+            ident = {c: np.arange(int(lens[k])) for k, c in enumerate(sp.mids)}        # placeholder order: idx only
+            ig, cg, iv, _, cen = pl.plan_finalize(tl, sp, ident, keep, layA_, layB_, placement, 0, layA_.size)
+            ig_d, cg_d, iv_d = ops.to_device_packed([ig, cg, iv])
+            return (layA_, layB_, ig_d, len(ig), cg_d, len(cg), iv_d, len(iv),
+                    ops.upload_tasks(cen) if cen is not None else None)
+        layA, layB, iso_g_d, n_ig, cen_g_d, n_cg, iso_v_d, n_iv, cen_dev = self._cached(
+            ("fin", placement, bl.key(), br.key(), counts.tobytes()), build_fin)
         offA, offB = 0, layA.size
-        iso_g, cen_g, iso_v, idx, cen_tasks = pl.plan_finalize(tl, sp, order, keep, layA, layB, placement, offA, offB)
+        idx = np.concatenate([order[c][:keep[c]] for c in sp.mids if keep[c] > 0]).astype(np.int32) if kept_tot else \
+            np.zeros(1, dtype=np.int32)
         out = ops.zeros_z(max(layA.size + layB.size, 1))
-        idx_d, iso_g_d, cen_g_d, iso_v_d = ops.to_device_packed([idx, iso_g, cen_g, iso_v])    # one upload
-        if len(iso_g):
-            ops.batched_copy(out, G, idx_d, S, iso_g_d, len(iso_g), 1.0)
-        if len(cen_g):
-            ops.batched_copy(out, G, idx_d, S, cen_g_d, len(cen_g), 1.0 / nrm)
-        if len(iso_v):
-            ops.batched_copy(out, Vj, idx_d, S, iso_v_d, len(iso_v), 1.0)
-        if cen_tasks is not None:
-            cen_tasks.segs["alpha_re"] *= 1.0 / nrm
-            ops.grouped_gemm(self._bufs(x=x, s1=out, y=out), ops.upload_tasks(cen_tasks))
+        idx_d = ops.to_device(idx)
+        if n_ig:
+            ops.batched_copy(out, G, idx_d, S, iso_g_d, n_ig, 1.0)
+        if n_cg:
+            ops.batched_copy(out, G, idx_d, S, cen_g_d, n_cg, 1.0 / nrm)
+        if n_iv:
+            ops.batched_copy(out, Vj, idx_d, S, iso_v_d, n_iv, 1.0)
+        if cen_dev is not None:
+            x.mul_(1.0 / nrm) if hasattr(x, "mul_") else np.multiply(x, 1.0 / nrm, out=x)     # centre = U^H (M / nrm)
+            ops.grouped_gemm(self._bufs(x=x, s1=out, y=out), cen_dev)
         bufA, bufB = out[offA:offA + max(layA.size, 1)], out[offB:offB + max(layB.size, 1)]
         self.bonds[i + 1] = mid
         self.site_lay[i], self.site_buf[i] = layA, bufA
