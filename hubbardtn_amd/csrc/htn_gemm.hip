@@ -154,61 +154,125 @@ __global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, cons
     d4 acc_im = {0.0, 0.0, 0.0, 0.0};
 
     const bool presplit = T.pad[1] != 0;
-    // Cursor of this quad over the tile's flat slab sequence (quad q takes slabs q, q+4, q+8, ...).  The
-    // segment DESCRIPTOR of the slab after the one being fetched is loaded one round ahead, so the data loads
-    // of a round never wait for a descriptor (a cold 64-byte scalar load costs ~0.6 us on the critical path).
-    Cursor cur = {0, 0};
-    advance(cur, q, segs, T.seg_begin, n_gemm, presplit);
-    bool valid = cur.s < n_gemm;
-    htn_seg Sd = {};            // never read a descriptor that does not exist (a tile may own zero segments)
-    if (valid) Sd = segs[T.seg_begin + cur.s];
-    Slab regs;
-    load_slab(regs, bufs, T, Sd, cur, valid, tq);
-    Cursor nxt = cur;
-    bool nvalid = false;
-    if (valid) {
-        advance(nxt, NQ, segs, T.seg_begin, n_gemm, presplit);
-        nvalid = nxt.s < n_gemm;
-    }
-    htn_seg Sn = {};
-    if (nvalid) Sn = segs[T.seg_begin + nxt.s];
-    bool any = n_gemm > 0;
-    while (any) {
-        const int op_a = valid ? Sd.op_a : 0, op_b = valid ? Sd.op_b : 0;
-        const int kleft = valid ? Sd.k - cur.k0 : 0;
-        store_slab(regs, lds, op_a, op_b, tq);
-        __syncthreads();
-        const bool cur_valid = valid;
-        // the prefetched descriptor becomes current: issue the next slab's global loads before the MFMAs
-        cur = nxt;
-        valid = nvalid;
-        Sd = Sn;
+    if (presplit) {
+        // ---- pre-split tiles (what the planner emits): every GEMM segment IS one K slab, so quad q's slab t is
+        // segment q + NQ t and no cursor walk is needed.  Two slabs are in flight in registers (loaded two rounds
+        // before they are staged): the operand fetch -- L2 / Infinity-Cache latency, ~2-3 us under load -- hides
+        // behind TWO rounds of MFMAs instead of one (SQ_VALU_MFMA_BUSY was 28 % of the busy CU time with one).
+        const htn_seg* __restrict__ sg = segs + T.seg_begin;
+        const Cursor c0 = {0, 0};
+        int j = q;                                         // segment of the slab staged next
+        htn_seg D = {};
+        Slab r0, r1;
+        bool v0 = j < n_gemm, v1 = j + NQ < n_gemm, vn = j + 2 * NQ < n_gemm;
+        int oa0 = 0, ob0 = 0, k0 = 0, oa1 = 0, ob1 = 0, k1 = 0;
+        if (v0) {
+            D = sg[j];
+            oa0 = D.op_a, ob0 = D.op_b, k0 = D.k;
+        }
+        load_slab(r0, bufs, T, D, c0, v0, tq);
+        if (v1) {
+            D = sg[j + NQ];
+            oa1 = D.op_a, ob1 = D.op_b, k1 = D.k;
+        }
+        load_slab(r1, bufs, T, D, c0, v1, tq);
+        if (vn) D = sg[j + 2 * NQ];                          // descriptor of the slab loaded in the first round
+        bool any = n_gemm > 0;
+#define HTN_ROUND(RS, OA, OB, KK, VV)                                                                        \
+        {                                                                                                    \
+            store_slab(RS, lds, VV ? OA : 0, VV ? OB : 0, tq);                                               \
+            __syncthreads();                                                                                 \
+            const bool cur_valid = VV;                                                                       \
+            const int kleft = VV ? KK : 0;                                                                   \
+            /* the register slab just staged is free: fetch the slab two rounds ahead into it */            \
+            VV = vn;                                                                                         \
+            if (vn) OA = D.op_a, OB = D.op_b, KK = D.k;                                                      \
+            load_slab(RS, bufs, T, D, c0, vn, tq);                                                           \
+            j += NQ;                                                                                         \
+            vn = j + 2 * NQ < n_gemm;                                                                        \
+            if (cur_valid) {                                                                                 \
+                const int ksteps = kleft >= KB ? KB / 4 : (kleft + 3) >> 2;                                  \
+                for (int ks = 0; ks < ksteps; ++ks) {                                                        \
+                    const int kk = ks * 4 + l4;                                                              \
+                    const double b_re = lds[2 * SLAB + LDS_AT(kk, wc * 16 + l15)];                           \
+                    const double b_im = lds[3 * SLAB + LDS_AT(kk, wc * 16 + l15)];                           \
+                    const double a_re = lds[0 * SLAB + LDS_AT(kk, wr * 16 + l15)];                           \
+                    const double a_im = lds[1 * SLAB + LDS_AT(kk, wr * 16 + l15)];                           \
+                    acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_re, acc_re, 0, 0, 0);              \
+                    acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-b_im, a_im, acc_re, 0, 0, 0);             \
+                    acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_im, acc_im, 0, 0, 0);              \
+                    acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_im, a_re, acc_im, 0, 0, 0);              \
+                }                                                                                            \
+            }                                                                                                \
+            /* descriptor of the slab the NEXT round loads: after the MFMA phase (scalar loads share lgkmcnt with  \
+               the LDS operand reads), its latency hides behind the barrier and the next staging */         \
+            if (vn) D = sg[j + 2 * NQ];                                                                      \
+        }
+        while (any) {
+            HTN_ROUND(r0, oa0, ob0, k0, v0)
+            any = __syncthreads_or(v1 ? 1 : 0) != 0;          // is there a slab left to stage? (also fences LDS reuse)
+            if (!any) break;
+            HTN_ROUND(r1, oa1, ob1, k1, v1)
+            any = __syncthreads_or(v0 ? 1 : 0) != 0;
+        }
+#undef HTN_ROUND
+    } else {
+        // Cursor of this quad over the tile's flat slab sequence (quad q takes slabs q, q+4, q+8, ...).  The
+        // segment DESCRIPTOR of the slab after the one being fetched is loaded one round ahead, so the data loads
+        // of a round never wait for a descriptor (a cold 64-byte scalar load costs ~0.6 us on the critical path).
+        Cursor cur = {0, 0};
+        advance(cur, q, segs, T.seg_begin, n_gemm, presplit);
+        bool valid = cur.s < n_gemm;
+        htn_seg Sd = {};            // never read a descriptor that does not exist (a tile may own zero segments)
+        if (valid) Sd = segs[T.seg_begin + cur.s];
+        Slab regs;
         load_slab(regs, bufs, T, Sd, cur, valid, tq);
-        nvalid = false;
+        Cursor nxt = cur;
+        bool nvalid = false;
         if (valid) {
-            nxt = cur;
             advance(nxt, NQ, segs, T.seg_begin, n_gemm, presplit);
             nvalid = nxt.s < n_gemm;
         }
-        if (cur_valid) {
-            const int ksteps = kleft >= KB ? KB / 4 : (kleft + 3) >> 2;
-            for (int ks = 0; ks < ksteps; ++ks) {
-                const int kk = ks * 4 + l4;
-                const double b_re = lds[2 * SLAB + LDS_AT(kk, wc * 16 + l15)];   // Aop[i][k] = B[k][c0+i]
-                const double b_im = lds[3 * SLAB + LDS_AT(kk, wc * 16 + l15)];
-                const double a_re = lds[0 * SLAB + LDS_AT(kk, wr * 16 + l15)];   // Bop[k][j] = A[r0+j][k]
-                const double a_im = lds[1 * SLAB + LDS_AT(kk, wr * 16 + l15)];
-                acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_re, acc_re, 0, 0, 0);
-                acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-b_im, a_im, acc_re, 0, 0, 0);
-                acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_im, acc_im, 0, 0, 0);
-                acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_im, a_re, acc_im, 0, 0, 0);
-            }
-        }
-        // descriptor of the slab after next: issued AFTER the MFMA phase -- scalar loads share lgkmcnt with the LDS
-        // reads of the MFMA operands, so an earlier issue would stall the first MFMA on this cold load; here its
-        // latency hides behind the barrier and the next round's LDS staging
+        htn_seg Sn = {};
         if (nvalid) Sn = segs[T.seg_begin + nxt.s];
-        any = __syncthreads_or(valid ? 1 : 0) != 0;     // also fences LDS reuse
+        bool any = n_gemm > 0;
+        while (any) {
+            const int op_a = valid ? Sd.op_a : 0, op_b = valid ? Sd.op_b : 0;
+            const int kleft = valid ? Sd.k - cur.k0 : 0;
+            store_slab(regs, lds, op_a, op_b, tq);
+            __syncthreads();
+            const bool cur_valid = valid;
+            // the prefetched descriptor becomes current: issue the next slab's global loads before the MFMAs
+            cur = nxt;
+            valid = nvalid;
+            Sd = Sn;
+            load_slab(regs, bufs, T, Sd, cur, valid, tq);
+            nvalid = false;
+            if (valid) {
+                nxt = cur;
+                advance(nxt, NQ, segs, T.seg_begin, n_gemm, presplit);
+                nvalid = nxt.s < n_gemm;
+            }
+            if (cur_valid) {
+                const int ksteps = kleft >= KB ? KB / 4 : (kleft + 3) >> 2;
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    const int kk = ks * 4 + l4;
+                    const double b_re = lds[2 * SLAB + LDS_AT(kk, wc * 16 + l15)];   // Aop[i][k] = B[k][c0+i]
+                    const double b_im = lds[3 * SLAB + LDS_AT(kk, wc * 16 + l15)];
+                    const double a_re = lds[0 * SLAB + LDS_AT(kk, wr * 16 + l15)];   // Bop[k][j] = A[r0+j][k]
+                    const double a_im = lds[1 * SLAB + LDS_AT(kk, wr * 16 + l15)];
+                    acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_re, acc_re, 0, 0, 0);
+                    acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-b_im, a_im, acc_re, 0, 0, 0);
+                    acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_im, acc_im, 0, 0, 0);
+                    acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_im, a_re, acc_im, 0, 0, 0);
+                }
+            }
+            // descriptor of the slab after next: issued AFTER the MFMA phase -- scalar loads share lgkmcnt with the LDS
+            // reads of the MFMA operands, so an earlier issue would stall the first MFMA on this cold load; here its
+            // latency hides behind the barrier and the next round's LDS staging
+            if (nvalid) Sn = segs[T.seg_begin + nxt.s];
+            any = __syncthreads_or(valid ? 1 : 0) != 0;     // also fences LDS reuse
+        }
     }
     // ---- COPY segments: C += alpha * X tile, spread over the quads (each adds into its partial) ----
     // this lane's outputs are C[r0 + l15][c0 + l4 + 4 r], r = 0..3
