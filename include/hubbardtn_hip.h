@@ -129,9 +129,13 @@ int htn_lanczos_z(const htn_gemm_launch* stages_host, int32_t n_stages, int32_t 
  * Vj + v_off[i] (ld = n_i).  The caller stages M or M^H (htn_batched_copy_z) so that the isometry the
  * sweep direction needs is the normalised G*J itself; the other factor is then a plain GEMM with M.
  * desc: device array of htn_svd_block, desc_host: the same array in host memory (may be NULL: then every block
- * runs on ONE CU; with it, QRCP blocks larger than one CU's LDS use a multi-launch block-Jacobi over several CUs
- * and the call synchronises the stream once per outer sweep); max_m_host = max_i m_i (<= 512 in this version).
- * info_dev[i] receives the sweep count (<0: not converged). */
+ * runs on ONE CU; with it, QRCP blocks larger than one CU's LDS take the large-block path: panel-blocked pivoted QR,
+ * then block Jacobi whose panel-pair visits run on many CUs, one kernel launch per tournament round, convergence
+ * decided on the device; the small blocks run beside it on an internal second stream that joins `stream` before the
+ * call returns; the call blocks the host until the sweeps have converged, results stay on the device);
+ * max_m_host = max_i max(m_i, pad_i) (<= 512 in this version).
+ * info_dev[i] receives the sweep count (<0: not converged).  A sweep ends the iteration when the largest squared
+ * cosine it SAW before rotating was <= max(tol^2, 0.1 tol) (quadratic convergence: it leaves < tol^2 behind). */
 #define HTN_SVD_ACCUMULATE 1      /* flags: also accumulate the rotation J (else Vj is not touched) */
 #define HTN_SVD_QRCP 2            /* flags: the block at g_off is G0 (pad x m, ld = pad); pivoted-QR precondition it,
                                      run Jacobi on R^H (m x n, n = min(pad, m)) and write the m x n result
