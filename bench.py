@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--profile", action="store_true", help="sync-bracketed per-stage host timers (perturbs timing)")
     ap.add_argument("--lanczos-tol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-bonds", type=int, default=1)
+    ap.add_argument("--cpu-bonds", type=int, default=12,
+                    help="centre-bond updates the numpy oracle is timed on (about 0.85 s each at chi=1024 on one BLAS thread: a ~10 s sample)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--rank-cut", type=float, default=None,
                     help="engine.rank_cut (default 0 = off, full 1e-8 parity of every kept Schmidt value): fraction of the "
@@ -229,11 +230,24 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "one_band":
         try:
             work = sum(s.n_matvec * s.apply_flops + s.svd_flops for s in stats) / args.steps
-            cdt, cst, i0 = cpu_baseline(eng, L, t, u, args.lanczos_tol, args.cpu_bonds, log)
+            # the oracle's dense algebra is numpy -> OpenBLAS / LAPACK, which would silently use every host core: pin
+            # it to ONE thread (the reference runs 1 BLAS thread per task, src:28-39) so that `cores` is what ran
+            ncores = 1
+            try:
+                from threadpoolctl import threadpool_limits
+                limiter = threadpool_limits(limits=1)
+            except Exception:
+                limiter = None
+                ncores = os.cpu_count() or 1
+            try:
+                cdt, cst, i0 = cpu_baseline(eng, L, t, u, args.lanczos_tol, args.cpu_bonds, log)
+            finally:
+                if limiter is not None:
+                    limiter.restore_original_limits()
             # work of the sampled bond in the same model, taken from the engine's own stats of that bond
             sb = [s for s in stats if s.bond == i0 + 1]
             wb = np.mean([s.n_matvec * s.apply_flops + s.svd_flops for s in sb])
-            out["cpu_baseline"] = {"value": cdt * work / wb, "unit": "s", "cores": int(os.environ.get("OMP_NUM_THREADS", "1")),
+            out["cpu_baseline"] = {"value": cdt * work / wb, "unit": "s", "cores": ncores,
                                    "kind": "port",
                                    "sample": f"{args.cpu_bonds} update(s) of centre bond {i0 + 1} of the same chi={args.chi} state "
                                              f"by the numpy oracle ({cdt:.2f} s each), scaled to a sweep by the recorded "
