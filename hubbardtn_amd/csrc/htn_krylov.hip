@@ -140,6 +140,91 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__
     }
 }
 
+// first Gram-Schmidt update FUSED with the second pass's dots: c = reduce(partial_in); w += sign * V c; and, while the
+// basis values of the element are still in registers, partial_out[i][b] = sum over slice b of conj(V_i) * w_new.
+// One read of the Krylov basis instead of two (the basis is the traffic of a Lanczos step: (j+1) x |theta|).
+// 256 threads = one wave per SIMD, so the CH basis values + 2 CH accumulators per thread fit the register file.
+template <int CH>
+__global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__ w, const double2* __restrict__ V,
+                                                           int64_t ldv, int nvec,
+                                                           const double2* __restrict__ partial_in,
+                                                           double2* __restrict__ c_out, int c_index, double sign,
+                                                           int64_t n, double2* __restrict__ partial_out) {
+    __shared__ double cs[64][2];
+    __shared__ double red[DOT_THREADS / 64][CH][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = wave; i < nvec; i += DOT_THREADS / 64) {
+        const double2 r = reduce_partials(partial_in + (int64_t)i * DOT_BLOCKS, lane);
+        if (lane == 0) {
+            cs[i][0] = r.x;
+            cs[i][1] = r.y;
+            if (blockIdx.x == 0 && i == c_index) *c_out = r;
+        }
+    }
+    if (tid >= nvec && tid < 64) cs[tid][0] = cs[tid][1] = 0.0;
+    __syncthreads();
+    const int64_t per = (n + DOT_BLOCKS - 1) / DOT_BLOCKS;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < n ? lo + per : n;
+    double ar[CH], ai[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) ar[c] = ai[c] = 0.0;
+    for (int64_t j = lo + tid; j < hi; j += DOT_THREADS) {
+        double2 v[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = c < nvec ? c : nvec - 1;
+            v[c] = V[(int64_t)i * ldv + j];
+        }
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {                // cs[c] = 0 beyond nvec
+            sr += cs[c][0] * v[c].x - cs[c][1] * v[c].y;
+            si += cs[c][0] * v[c].y + cs[c][1] * v[c].x;
+        }
+        double2 x = w[j];
+        x.x += sign * sr;
+        x.y += sign * si;
+        w[j] = x;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            ar[c] += v[c].x * x.x + v[c].y * x.y;     // conj(v) * w_new
+            ai[c] += v[c].x * x.y - v[c].y * x.x;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const double r = wave_sum(ar[c]);
+        const double m = wave_sum(ai[c]);
+        if (lane == 0) {
+            red[wave][c][0] = r;
+            red[wave][c][1] = m;
+        }
+    }
+    __syncthreads();
+    if (tid < CH && tid < nvec) {                     // fixed order over the 4 waves: deterministic
+        double r = 0.0, m = 0.0;
+#pragma unroll
+        for (int q = 0; q < DOT_THREADS / 64; ++q) {
+            r += red[q][tid][0];
+            m += red[q][tid][1];
+        }
+        partial_out[(int64_t)tid * DOT_BLOCKS + blockIdx.x] = make_double2(r, m);
+    }
+}
+
+static void launch_axpy_dots(double2* w, const double2* V, int64_t ldv, int nvec, const double2* partial_in, double2* c_out,
+                             int c_index, double sign, int64_t n, double2* partial_out, hipStream_t st) {
+#define HTN_AD(CHV)                                                                                              \
+    hipLaunchKernelGGL(k_axpy_dots<CHV>, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, ldv, nvec, partial_in, c_out, \
+                       c_index, sign, n, partial_out)
+    if (nvec <= 4) HTN_AD(4);
+    else if (nvec <= 8) HTN_AD(8);
+    else if (nvec <= 16) HTN_AD(16);
+    else HTN_AD(32);
+#undef HTN_AD
+}
+
 // dst = src / sqrt(sum norm_partial); block 0 writes the squared norm to nrm2_out (may be null)
 __global__ __launch_bounds__(DOT_THREADS) void k_scale_by_norm(double2* __restrict__ dst, const double2* __restrict__ src,
                                                                const double* __restrict__ norm_partial, int64_t n,
@@ -315,8 +400,8 @@ static void tridiag_lowest(const std::vector<double>& alpha, const std::vector<d
 }
 
 extern "C" int64_t htn_lanczos_scratch_elems(int32_t krylovdim) {
-    // partial sums (krylovdim+1 vectors) + c1 + c2 + y (each krylovdim+1) + norm partials / nrm2 (as doubles)
-    return (int64_t)(krylovdim + 1) * DOT_BLOCKS + 3 * (krylovdim + 1) + DOT_BLOCKS + 8;
+    // 2 x partial sums (krylovdim+1 vectors) + c1 + c2 + y (each krylovdim+1) + norm partials / nrm2 (as doubles)
+    return 2 * (int64_t)(krylovdim + 1) * DOT_BLOCKS + 3 * (krylovdim + 1) + DOT_BLOCKS + 8;
 }
 
 extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, int32_t x_slot, int32_t y_slot,
@@ -329,7 +414,8 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
     if (kd < 2 || kd > 63) return fail_msg("htn_lanczos_z: krylovdim must be in 2..63");
     double2* V = (double2*)Vv;
     double2* partial = (double2*)scratch;
-    double2* c1 = partial + (int64_t)(kd + 1) * DOT_BLOCKS;
+    double2* partial2 = partial + (int64_t)(kd + 1) * DOT_BLOCKS;
+    double2* c1 = partial2 + (int64_t)(kd + 1) * DOT_BLOCKS;
     double2* c2 = c1 + (kd + 1);
     double2* ycoef = c2 + (kd + 1);
     double* norm_partial = (double*)(ycoef + (kd + 1));
@@ -376,11 +462,10 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         if (matvec_ms_host) HIP_TRY(hipEventRecord(ev_mv0[j], st));
         if (matvec(vj, w)) return 1;
         if (matvec_ms_host) HIP_TRY(hipEventRecord(ev_mv1[j], st));
+        // two-pass classical Gram-Schmidt in three passes over the basis: dots | update + dots (fused) | update + norm
         launch_dots_partial(V, n, j + 1, w, n, partial, st);
-        hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial, c1 + j, j,
-                           -1.0, n, norm_partial);
-        launch_dots_partial(V, n, j + 1, w, n, partial, st);
-        hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial, c2 + j, j,
+        launch_axpy_dots(w, V, n, j + 1, partial, c1 + j, j, -1.0, n, partial2, st);
+        hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial2, c2 + j, j,
                            -1.0, n, norm_partial);
         hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, w, w, norm_partial, n, nrm2 + j);
         HIP_TRY(hipEventRecord(ev_done[j], st));
