@@ -63,7 +63,7 @@ class IDMRG2:
     verbosity: int = 0
     krylovdim: int = 30
     eigsolve_tol: float = 1e-10
-    sweeps_per_step: int = 4       # finite sweeps of the 2-cell window per growth step
+    sweeps_per_step: int = 6       # at most this many finite sweeps of the 2-cell window per growth step
 
 
 @dataclass

@@ -68,7 +68,7 @@ class IDMRGResult:
     engine: object = None        # the last window's engine (device-resident tensors of two unit cells)
 
 
-def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_per_step=2, init_dimension=8,
+def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_per_step=6, init_dimension=8,
            krylovdim=30, lanczos_tol=1e-10, seed=1234, verbosity=0, min_steps=3):
     """-> IDMRGResult.  `sim` is an OB_Sim / MB_Sim (filling P/Q); truncation by truncdim(chi_full) and/or
     truncbelow(cutoff) exactly as in the finite engine."""
@@ -99,8 +99,14 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
         bonds, tensors = mps.random_window(W, Llay.bond.dims, Rlay.bond.dims, init_dimension, seed=seed + it)
         eng = _engine.DMRG2(ops, mpo, bonds, tensors, chi_full=chi_full, cutoff=cutoff, krylovdim=krylovdim,
                             lanczos_tol=lanczos_tol, left_env=(Llay, Lbuf), right_env=(Rlay, Rbuf))
-        for _ in range(sweeps_per_step):
-            eng.sweep()
+        # the window starts from a random state: sweep until its energy has settled (at least twice, at most
+        # sweeps_per_step times); a window that has not found its ground state poisons the blocks it is absorbed into
+        E_sw = None
+        for k in range(sweeps_per_step):
+            E_new = eng.sweep()
+            if k >= 1 and E_sw is not None and abs(E_new - E_sw) <= 1e-11 * max(abs(E_new), 1.0):
+                break
+            E_sw = E_new
         # the leftward pass visited the centre bond last: its eigenvalue is the energy of system_n
         centre = [s for s in eng.stats if s.bond == T][-1]
         E = centre.energy
