@@ -87,6 +87,9 @@ class HipOps:
     def zero(self, t):
         t.zero_()
 
+    def scale_inplace(self, t, f: float):
+        t.mul_(f)
+
     def sync(self):
         self.torch.cuda.current_stream().synchronize()
 

@@ -342,7 +342,7 @@ class DMRG2:
         if n_iv:
             ops.batched_copy(out, Vj, idx_d, S, iso_v_d, n_iv, 1.0)
         if cen_dev is not None:
-            x.mul_(1.0 / nrm) if hasattr(x, "mul_") else np.multiply(x, 1.0 / nrm, out=x)     # centre = U^H (M / nrm)
+            ops.scale_inplace(x, 1.0 / nrm)                      # centre = U^H (M / nrm)
             ops.grouped_gemm(self._bufs(x=x, s1=out, y=out), cen_dev)
         bufA, bufB = out[offA:offA + max(layA.size, 1)], out[offB:offB + max(layB.size, 1)]
         self.bonds[i + 1] = mid

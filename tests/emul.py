@@ -40,6 +40,9 @@ class NumpyOps:
     def zero(self, t):
         t[...] = 0
 
+    def scale_inplace(self, t, f):
+        t *= f
+
     def sync(self):
         pass
 
