@@ -1,4 +1,4 @@
-"""scratch driver: iDMRG energy density vs the reference's infinite-chain test constants (test/OB.jl) on the GPU"""
+"""IDMRG2 energy densities against the reference test constants (test/OB.jl) with the reference truncation, on the GPU"""
 import sys, time
 sys.path.insert(0, ".")
 from hubbardtn_amd import models, idmrg
