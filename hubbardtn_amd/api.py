@@ -197,21 +197,82 @@ def compute_groundstate(simul: Simulation, L: int | None = None, tol: float = 1e
 
 
 def produce_groundstate(simul: Simulation, force: bool = False, **kw):
-    """src:1145-1166 without the DrWatson disk cache (out of scope): always computes"""
-    return compute_groundstate(simul, **kw)
+    """src:1145-1166: computes, or loads the result saved under the reference's cache name (storage.produce_or_load)"""
+    from . import storage
+    return storage.produce_or_load(compute_groundstate, simul, force=force, **kw)
 
 
 def expectation_value(psi: FiniteMPS, H):
-    """energy per site as a length-L vector whose sum / L is E/L (examples/One_band.jl:42-43 take
-    sum(real(E0)) / length(H)); the finite engine knows the total energy from its last eigensolve."""
+    """<psi|H|psi> per site as a vector whose sum / length(H) is the energy per site (examples/One_band.jl:42-43 take
+    sum(real(E0)) / length(H); test/OB.jl:28-29).  Finite chain: a genuine expectation value of the state AS STORED
+    (after truncation), evaluated by a non-optimising pass through the library; entry i = energy of the terms ending on
+    site i (engine.DMRG2.site_energies).  Infinite chain: the energy density of the converged window, the same for
+    every site of the unit cell: differences of <psi_n|H_n|psi_n> of successive (truncated) window states."""
     if isinstance(psi, InfiniteMPS):
         if psi.result is None:
             raise RuntimeError("run find_groundstate first")
         return np.full(len(H), psi.result.energy_per_site)
-    E = psi.engine.energy
-    if E is None:
+    if psi.engine.energy is None:
         raise RuntimeError("run find_groundstate first")
-    return np.full(psi.L, E / psi.L)
+    return psi.engine.site_energies()
+
+
+def _save_result(res, entry):
+    """cache entry of produce_groundstate: the site tensors (storage.save_state format) + what re-creates the handle"""
+    import json
+    import os
+    from . import storage
+    psi = res["groundstate"]
+    storage.save_state(psi, os.path.dirname(entry), os.path.basename(entry))
+    meta = {"delta": float(res["delta"])}
+    if isinstance(psi, InfiniteMPS):
+        r = psi.result
+        meta.update(kind="infinite", energy_per_site=r.energy_per_site, iterations=r.iterations, unit_cell=r.unit_cell,
+                    history=[list(h) for h in r.history], max_dimension=psi.max_dimension, seed=psi.seed,
+                    spectrum=[[N, j, [float(x) for x in v]] for (N, j), v in sorted(r.spectrum.items())],
+                    bL=[[N, j, n] for (N, j), n in sorted(r.boundary["bL"].items())],
+                    bR=[[N, j, n] for (N, j), n in sorted(r.boundary["bR"].items())],
+                    chi_full=r.engine.chi_full, cutoff=r.engine.cutoff)
+        np.save(os.path.join(entry, "left_env.npy"), r.boundary["Lenv"])
+        np.save(os.path.join(entry, "right_env.npy"), r.boundary["Renv"])
+    else:
+        eng = psi.engine
+        meta.update(kind="finite", L=psi.L, energy=eng.energy, chi_full=eng.chi_full, cutoff=eng.cutoff)
+    with open(os.path.join(entry, "result.json"), "w") as f:
+        json.dump(meta, f)
+
+
+def _load_result(simul, entry, L=None, ops=None, **kw):
+    """the result dictionary of compute_groundstate re-created from a cache entry: the state is uploaded, nothing is
+    recomputed"""
+    import json
+    import os
+    from . import storage
+    meta = json.load(open(os.path.join(entry, "result.json")))
+    bonds, sites = storage.load_state(entry)
+    tensors = [s["blocks"] for s in sites]
+    H = hamiltonian(simul, L)
+    ops = ops or _ops()
+    if meta["kind"] == "infinite":
+        T = meta["unit_cell"]
+        big = models.hamiltonian(simul, 8 * _idmrg.unit_cell(simul.P, simul.Q))
+        window = [big[3 * T + i] for i in range(2 * T)]
+        eng = _engine.DMRG2(ops, window, bonds, tensors, chi_full=meta["chi_full"], cutoff=meta["cutoff"],
+                            left_env=np.load(os.path.join(entry, "left_env.npy")),
+                            right_env=np.load(os.path.join(entry, "right_env.npy")))
+        spec = {(N, j): np.asarray(v) for N, j, v in meta["spectrum"]}
+        res = _idmrg.IDMRGResult(energy_per_site=meta["energy_per_site"], delta=meta["delta"], iterations=meta["iterations"],
+                                 unit_cell=T, bond_dims=eng.bond_dims(), spectrum=spec,
+                                 history=[tuple(h) for h in meta["history"]], engine=eng,
+                                 boundary={"bL": {(N, j): n for N, j, n in meta["bL"]}, "bR": {(N, j): n for N, j, n in meta["bR"]},
+                                           "Lenv": np.load(os.path.join(entry, "left_env.npy")),
+                                           "Renv": np.load(os.path.join(entry, "right_env.npy"))})
+        psi = InfiniteMPS(meta["max_dimension"], meta["seed"], ops, res)
+        return {"groundstate": psi, "environments": Environments(eng), "ham": H, "delta": meta["delta"], "config": simul}
+    eng = _engine.DMRG2(ops, H, bonds, tensors, chi_full=meta["chi_full"], cutoff=meta["cutoff"])
+    eng.energy = meta["energy"]
+    psi = FiniteMPS(eng, meta["L"])
+    return {"groundstate": psi, "environments": Environments(eng), "ham": H, "delta": meta["delta"], "config": simul}
 
 
 def dim_state(psi: FiniteMPS):

@@ -3,12 +3,6 @@
 // launches HIP kernels.  See DESIGN.md for the data layout and the roofline bounding each kernel.
 #include "htn_common.h"
 
-static thread_local char g_err[512] = "";
-char* htn_err_buf() { return g_err; }
-
-extern "C" const char* htn_last_error(void) { return g_err; }
-extern "C" int htn_abi_version(void) { return HTN_ABI_VERSION; }
-
 extern "C" int htn_device_init(int device, char* name_host, int* cu_count_host) {
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t p;

@@ -406,7 +406,7 @@ extern "C" int64_t htn_lanczos_scratch_elems(int32_t krylovdim) {
 
 extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, int32_t x_slot, int32_t y_slot,
                              void* Vv, int64_t n, int32_t krylovdim, double tol, int32_t max_restart,
-                             void* scratch, int32_t zero_y, htn_exchange_fn exchange, void* user,
+                             void* scratch, int32_t zero_y, htn_exchange2_fn exchange, void* user,
                              double* eig_host, int32_t* n_matvec_host, double* residual_host,
                              double* matvec_ms_host, void* stream_v) {
     hipStream_t st = (hipStream_t)stream_v;
@@ -452,7 +452,7 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
             bufs[y_slot] = y;
             if (htn_grouped_gemm_z(bufs, stages[s].tiles, stages[s].n_tiles, stages[s].segs, st)) return 1;
         }
-        if (exchange) exchange(y, n, user);
+        if (exchange && exchange(y, n, user)) return fail_msg("htn_lanczos_z: the exchange hook reported a failure");
         return 0;
     };
     // one Lanczos step, fully enqueued: w = H v_j; two Gram-Schmidt passes against V[0..j]; v_{j+1} = w/|w|
@@ -478,7 +478,7 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
                        (double*)nullptr);
     double mv_ms = 0.0;
     int nmv = 0;
-    double theta = 0.0, res = 0.0, beta = 0.0;
+    double theta = 0.0, res = 0.0, beta = 0.0, amax = 0.0;
     std::vector<double> y;
     for (int restart = 0; restart <= max_restart; ++restart) {
         std::vector<double> alphas, betas;
@@ -503,7 +503,9 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
             alphas.push_back(alpha);
             tridiag_lowest(alphas, betas, &theta, y);
             res = fabs(beta * y.back());
-            if (res < tol || beta < 1e-14 || j == kd - 1) break;
+            amax = std::max(amax, std::max(fabs(alpha), beta));
+            // invariant subspace: beta negligible RELATIVE to the scale of the tridiagonal matrix
+            if (res < tol || beta < 1e-14 * std::max(amax, 1e-300) || j == kd - 1) break;
             betas.push_back(beta);
         }
         HIP_TRY(hipStreamSynchronize(st));       // drain the speculative step before rows are reused
@@ -518,7 +520,7 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, V, xrow, norm_partial, n,
                            (double*)nullptr);
         HIP_TRY(hipStreamSynchronize(st));      // h_y is reused by the next restart / call
-        if (res < tol || beta < 1e-14) break;
+        if (res < tol || beta < 1e-14 * std::max(amax, 1e-300)) break;
     }
     HIP_TRY(hipGetLastError());
     *eig_host = theta;

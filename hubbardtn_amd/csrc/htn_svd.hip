@@ -1,4 +1,5 @@
 // batched Jacobi SVD + strided copy kernels (libhubbardtn_hip.so)
+#include <mutex>
 #include <algorithm>
 #include <vector>
 
@@ -1219,42 +1220,34 @@ static int js_reserve(size_t dev_bytes, size_t pin_bytes) {
     return 0;
 }
 
-// elements of R^H above which a QRCP block leaves the one-workgroup kernel for the multi-kernel path; the default
-// (0) is "does not fit the LDS window".  Lower values exist to exercise the large-block path on small problems.
-static int g_jac_split = 0;
-// absolute cut of the rank-revealing QR of the large blocks (0 = off): directions whose singular values are all below
-// it (squared Frobenius mass of the unfactorised part <= cut^2) are dropped before the Jacobi sweeps; their singular
-// values are reported as 0.  The caller chooses it from what it is going to truncate anyway.
-static double g_jac_cut = 0.0;
-extern "C" double htn_jacobi_set_rank_cut(double abs_cut) {
-    const double prev = g_jac_cut;
-    g_jac_cut = abs_cut > 0.0 ? abs_cut : 0.0;
-    return prev;
-}
-
-extern "C" int32_t htn_jacobi_set_split(int32_t elems) {
-    const int32_t prev = g_jac_split;
-    g_jac_split = elems > 0 ? elems : 0;
-    return prev;
-}
-
 extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc,
                                 const htn_svd_block* desc_host, int32_t n_blocks, int32_t max_m_host,
-                                int32_t max_sweeps, double tol, int32_t* info_dev, void* stream) {
+                                int32_t max_sweeps, double tol, int32_t* info_dev, const htn_svd_opts* opts,
+                                void* stream) {
     if (n_blocks <= 0) return 0;
+    // per-call settings (ABI 2): nothing process-wide is read or written here
+    const int g_jac_split = opts && opts->split_elems > 0 ? opts->split_elems : 0;
+    const double g_jac_cut = opts && opts->rank_cut > 0.0 ? opts->rank_cut : 0.0;
     if (max_m_host > 64 * JAC_MAXEL) return fail_msg("htn_jacobi_svd_z: block taller than 512 rows");
     hipStream_t st = (hipStream_t)stream;
     // dynamic LDS window for the matrix: 144 KiB leaves room for the static shared variables
     const int lds_elems = 9216;     // complex128 elements = 144 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_svd, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    lds_elems * (int)sizeof(double2)));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_qr_large, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    16 * (64 * JAC_MAXEL + 1) * (int)sizeof(double2)));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_pairs_gram, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (16 * (64 * JAC_MAXEL + 1) + 4 * 16 * JG_LD) * (int)sizeof(double2)));
-        attr_set = true;
+    // one-time kernel attributes: per device and thread safe (the attribute lives with the device's code object)
+    {
+        static std::mutex attr_mu;
+        static bool attr_set[64] = {};
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(attr_mu);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_svd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        lds_elems * (int)sizeof(double2)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_qr_large, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        16 * (64 * JAC_MAXEL + 1) * (int)sizeof(double2)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_pairs_gram, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (16 * (64 * JAC_MAXEL + 1) + 4 * 16 * JG_LD) * (int)sizeof(double2)));
+            attr_set[dev] = true;
+        }
     }
     // blocks that do not fit one CU's LDS go to the multi-launch block-Jacobi path (needs the host copy of desc)
     const int large_min = g_jac_split > 0 ? std::min(g_jac_split, lds_elems) : lds_elems;

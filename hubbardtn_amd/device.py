@@ -1,8 +1,10 @@
-"""Device primitives of the hot path: thin wrapper over the C ABI (hubbardtn_amd/abi.py).
+"""Context provider of the product path + thin wrappers over the kernel-level C ABI (hubbardtn_amd/abi.py).
 
-PyTorch is used only as plumbing: device memory (torch tensors), the current HIP stream and
-(in dist.py) torch.distributed.  Every compute call below goes through libhubbardtn_hip.so;
-if the library or the GPU is missing, construction raises.
+`HipOps.ctx` is the `htn_ctx` every engine object (hubbardtn_amd/engine.py) lives in: the library owns its stream,
+its device memory and -- for the sector-parallel apply -- its RCCL communicator (`set_comm`).  PyTorch is plumbing only:
+`torch.distributed` distributes the 128-byte RCCL id, and the kernel-level wrappers below (used by the kernel tests)
+take torch tensors as device memory.  Every compute call goes through libhubbardtn_hip.so; if the library or the GPU
+is missing, construction raises -- there is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -34,6 +36,48 @@ class HipOps:
         self._dots_scratch = None
         self._stream_ptr = None
         self.event_log = None        # bench.py: list of (start_event, end_event, tag, flops)
+        h = C.c_void_p()
+        abi.check(self.lib, self.lib.htn_ctx_create(abi.BACKEND_HIP, device, None, C.byref(h)), "htn_ctx_create")
+        self.ctx = h
+        self._cb = None
+        self._exc = None
+
+    def __del__(self):
+        h, self.ctx = getattr(self, "ctx", None), None
+        if h:
+            self.lib.htn_ctx_destroy(h)
+
+    # ---- context settings ---------------------------------------------------------------------
+    def set_timing(self, on: bool):
+        """HIP events around every H_eff apply launch (BondStats.matvec_ms)"""
+        abi.check(self.lib, self.lib.htn_ctx_set_timing(self.ctx, 1 if on else 0), "htn_ctx_set_timing")
+
+    def set_comm(self, rank: int, world: int, group=None):
+        """sector-parallel apply over `world` ranks: RCCL all-reduce inside the library.  The id is created on rank 0
+        and broadcast through torch.distributed (any initialised backend)."""
+        import torch.distributed as dist
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            abi.check(self.lib, self.lib.htn_comm_unique_id(ident), "htn_comm_unique_id")
+        if world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (C.c_char * 128).from_buffer_copy(box[0])
+        abi.check(self.lib, self.lib.htn_ctx_set_comm(self.ctx, rank, world, ident), "htn_ctx_set_comm")
+
+    def set_exchange(self, rank: int, world: int, fn):
+        """caller-supplied reduction: fn(y_ptr, n) must enqueue/perform the sum of y (n complex128 at device pointer
+        y_ptr) over the ranks.  Exceptions abort the solve (the C side sees a non-zero return) and are re-raised by
+        the next engine call through `check_exchange`."""
+        def _cb(y_ptr, n, user):
+            try:
+                fn(y_ptr, n)
+                return 0
+            except BaseException as e:      # noqa: BLE001 -- must not propagate through the C frame
+                self._exc = e
+                return 1
+        self._cb = abi.EXCHANGE_FN(_cb) if fn is not None else abi.EXCHANGE_FN()
+        abi.check(self.lib, self.lib.htn_ctx_set_exchange(self.ctx, rank, world, self._cb, None), "htn_ctx_set_exchange")
 
     # ---- memory -----------------------------------------------------------------------------
     def empty_z(self, n):
@@ -163,34 +207,38 @@ class HipOps:
             self._lan_scratch = self.empty_z(need)
         base = V.data_ptr()
 
+        err = []
+
         def _cb(y_ptr, nn, user):
-            off = (y_ptr - base) // 16
-            exchange(V[off:off + nn])
+            try:
+                off = (y_ptr - base) // 16
+                exchange(V[off:off + nn])
+                return 0
+            except BaseException as e:      # noqa: BLE001 -- a Python exception must not cross the C frame
+                err.append(e)
+                return 1
         cb = abi.EXCHANGE_FN(_cb) if exchange is not None else abi.EXCHANGE_FN()
         eig, nmv, res, ms = C.c_double(0.0), C.c_int32(0), C.c_double(0.0), C.c_double(0.0)
         timed = self.event_log is not None
-        abi.check(self.lib, self.lib.htn_lanczos_z(arr, len(stages), x_slot, y_slot, self._p(V), n, krylovdim,
-                                                   float(tol), max_restart, self._p(self._lan_scratch),
-                                                   1 if zero_y else 0, cb, None, C.byref(eig), C.byref(nmv),
-                                                   C.byref(res), C.byref(ms) if timed else None, self._stream()),
-                  "htn_lanczos_z")
+        rc = self.lib.htn_lanczos_z(arr, len(stages), x_slot, y_slot, self._p(V), n, krylovdim,
+                                    float(tol), max_restart, self._p(self._lan_scratch),
+                                    1 if zero_y else 0, cb, None, C.byref(eig), C.byref(nmv),
+                                    C.byref(res), C.byref(ms) if timed else None, self._stream())
+        if err:
+            raise err[0]
+        abi.check(self.lib, rc, "htn_lanczos_z")
         if timed:
             self.event_log.append(("matvec_ms", ms.value, nmv.value))
         return eig.value, nmv.value, res.value
 
-    def jacobi_svd(self, G, Vj, S, desc_dev, nblocks, max_m, max_sweeps, tol, info, desc_host=None):
+    def jacobi_svd(self, G, Vj, S, desc_dev, nblocks, max_m, max_sweeps, tol, info, desc_host=None, split=0, rank_cut=0.0):
+        """split: elements of R^H above which a block takes the large-block SVD path (0 = default);
+        rank_cut: absolute singular-value cut of the large blocks' rank-revealing QR (0 = off).  Per call (ABI 2)."""
         hp = C.c_void_p(desc_host.ctypes.data) if desc_host is not None else C.c_void_p(0)
+        opts = abi.SvdOpts(int(split), 0, float(rank_cut))
         abi.check(self.lib, self.lib.htn_jacobi_svd_z(self._p(G), self._p(Vj), self._p(S), self._p(desc_dev), hp,
                                                       nblocks, max_m, max_sweeps, float(tol), self._p(info),
-                                                      self._stream()), "htn_jacobi_svd_z")
-
-    def jacobi_set_split(self, elems: int) -> int:
-        """threshold (elements of R^H) above which a block takes the large-block SVD path; returns the previous one"""
-        return int(self.lib.htn_jacobi_set_split(int(elems)))
-
-    def jacobi_set_rank_cut(self, abs_cut: float) -> float:
-        """absolute singular-value cut of the large blocks' rank-revealing QR (0 = off); returns the previous one"""
-        return float(self.lib.htn_jacobi_set_rank_cut(float(abs_cut)))
+                                                      C.byref(opts), self._stream()), "htn_jacobi_svd_z")
 
     def batched_copy(self, dst, src, idx, scl, items_dev, nitems, gscale):
         if nitems == 0:

@@ -1,24 +1,21 @@
-"""Two-site DMRG sweep engine (finite chain) on the device primitives of hubbardtn_hip.h.
+"""Thin Python face of the C++ sweep engine (hubbardtn_amd/csrc/htn_engine.cpp behind include/hubbardtn_hip.h).
 
-Stands in for MPSKit's two-site sweep body reached from
-`find_groundstate(psi0, H, IDMRG2(; trscheme, tol))` (src/HubbardFunctions.jl:1010) -- per bond:
-form theta, Lanczos lowest eigenpair of the AC2 effective Hamiltonian, SVD + truncation, write
-back, move the environment.  The sweep schedule follows MPSKit's DMRG2:
-bonds 1..L-1 going right, then L-2..1 going left (2L-3 bond updates per sweep).
-
-All tensors stay on the device between bonds; the host sees only the Lanczos tridiagonal
-coefficients and the singular values (needed for the global truncation rule, App. A.6).
+Everything below `find_groundstate(psi0, H, alg)` (src/HubbardFunctions.jl:1010) -- sector layouts, recoupling
+coefficients, task lists, theta formation, Lanczos, per-sector SVD, the global truncation rule, write-back,
+environment transfer, the sweep loop -- runs inside the library (`htn_mps_create`, `htn_bond_update`,
+`htn_dmrg2_sweep`).  This module only converts the host-side model (list of models.MPOSite) and the initial state
+(bond tables + block dictionaries) into the ABI's tables and reads results back.
 """
 from __future__ import annotations
 
-import time
-from dataclasses import dataclass, field
+import ctypes as C
+from dataclasses import dataclass
 
 import numpy as np
 
-from . import planner as pl
-from .planner import (BUF_AUX, BUF_L, BUF_R, BUF_S1, BUF_S2, BUF_X, BUF_Y, BUF_Z, Bond, EnvLayout, SiteLayout,
-                      ThetaLayout)
+from . import abi
+from .models import SITE_MULT, SITE_OPS
+from .sectors import Bond
 
 
 @dataclass
@@ -43,346 +40,307 @@ class BondStats:
     t_lanczos: float = 0.0
     t_svd: float = 0.0
     t_env: float = 0.0
+    matvec_ms: float = 0.0
+
+
+def _stats(rec) -> BondStats:
+    return BondStats(**{k: (float(rec[k]) if rec.dtype[k].kind == "f" else int(rec[k])) for k in rec.dtype.names})
+
+
+class CMpo:
+    """htn_mpo handle built from a list of models.MPOSite (reduced SU(2) x U(1) x fZ2 operators)"""
+
+    def __init__(self, ops, sites):
+        self.ops, self.lib = ops, ops.lib
+        names = sorted({e[2] for s in sites for e in s.entries})
+        self.op_index = {n: k for k, n in enumerate(names)}
+        optab = np.zeros(max(len(names), 1), dtype=abi.SITE_OP_DT)
+        for n, k in self.op_index.items():
+            kk, dN, red = SITE_OPS[n]
+            optab[k]["k"], optab[k]["dN"] = kk, dN
+            r = np.zeros((abi.MAX_SITE, abi.MAX_SITE))
+            r[:red.shape[0], :red.shape[1]] = red
+            optab[k]["red"] = r.reshape(-1)
+        n = len(sites)
+        levels, level_ptr = [], [0]
+        bonds = [sites[0].left] + [s.right for s in sites]
+        for i in range(1, n):
+            if list(sites[i].left) != list(sites[i - 1].right):
+                raise ValueError(f"MPO bond {i}: left levels of site {i} differ from right levels of site {i - 1}")
+        for lv in bonds:
+            levels.extend(lv)
+            level_ptr.append(level_ptr[-1] + len(lv))
+        ent = np.zeros(max(sum(len(s.entries) for s in sites), 1), dtype=abi.MPO_ENTRY_DT)
+        entry_ptr, q = [0], 0
+        for s in sites:
+            for (wl, wr, name, coef) in s.entries:
+                c = complex(coef)
+                ent[q] = (wl, wr, self.op_index[name], 0, c.real, c.imag)
+                q += 1
+            entry_ptr.append(q)
+        sym = abi.Symmetry()
+        sym.kind, sym.n_site = abi.SYM_SU2_U1, len(SITE_MULT)
+        for s, (N, j) in enumerate(SITE_MULT):
+            sym.site_N[s], sym.site_j[s] = N, j
+        lv = np.ascontiguousarray(np.array(levels, dtype=np.int32).reshape(-1, 2))
+        lp = np.array(level_ptr, dtype=np.int32)
+        ep = np.array(entry_ptr, dtype=np.int32)
+        h = C.c_void_p()
+        abi.check(self.lib, self.lib.htn_mpo_create(ops.ctx, C.byref(sym), n, optab.ctypes.data, len(names), lp.ctypes.data,
+                                                    lv.ctypes.data, ep.ctypes.data, ent.ctypes.data, C.byref(h)),
+                  "htn_mpo_create")
+        self.handle = h
+        self.sites = sites
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.htn_mpo_destroy(h)
 
 
 class DMRG2:
-    """finite two-site DMRG on reduced SU(2) x U(1) tensors.
+    """finite two-site DMRG on reduced SU(2) x U(1) tensors -- handle of an `htn_mps` inside the library.
 
-    ops        : device primitive provider (hubbardtn_amd.device.HipOps in the product)
+    ops        : context provider (hubbardtn_amd.device.HipOps in the product; `.lib`, `.ctx`)
     mpo        : list[models.MPOSite]
     bonds      : list of {sector: count} for bonds 0..L (initial state)
     tensors    : list of {(l, s, r): ndarray[n_l, n_r]} right-canonical initial site tensors
     chi_full   : truncdim(D) in TensorKit's `dim` units (sum (2S+1) n), or None
     cutoff     : truncbelow(eta) Schmidt-value cut (10^-svalue, src:1007), or 0
-    shard      : optional (rank, world, allreduce_fn) for the sector-parallel apply
+    left_env / right_env : boundary environments (flat arrays in the library's block order, `env_data`) of an iDMRG
+                 window; None = open end
+    Sharding (sector-parallel apply) is a property of the context: HipOps.set_comm / set_exchange.
     """
 
     def __init__(self, ops, mpo, bonds, tensors, chi_full=None, cutoff=0.0, krylovdim=30, lanczos_tol=1e-12,
-                 maxrestart=3, weighting="sqrtdim", jacobi_tol=1e-14, jacobi_max_sweeps=40, shard=None,
-                 left_env=None, right_env=None):
-        self.ops, self.mpo = ops, mpo
-        self.L = len(mpo)
+                 maxrestart=3, weighting="sqrtdim", jacobi_tol=1e-14, jacobi_max_sweeps=40, left_env=None, right_env=None):
+        self.ops, self.lib = ops, ops.lib
+        self.cmpo = mpo if isinstance(mpo, CMpo) else CMpo(ops, mpo)
+        self.mpo = self.cmpo.sites
+        self.L = len(self.mpo)
         self.chi_full, self.cutoff, self.weighting = chi_full, cutoff, weighting
         self.krylovdim, self.lanczos_tol, self.maxrestart = krylovdim, lanczos_tol, maxrestart
         self.jacobi_tol, self.jacobi_max_sweeps = jacobi_tol, jacobi_max_sweeps
-        self.shard = shard
+        self.rank_cut = 0.0          # optional rank-revealing QR cut (OFF: the 1e-8 spectra parity needs it off), DESIGN.md 4
+        self.svd_split = 0           # tests: force small blocks through the large-block SVD path
         self.profile = False
-        # Optional rank-revealing cut of the blocks' pivoted QR (htn_jacobi_set_rank_cut): singular directions below
-        # rank_cut x (the smallest value the last update of the same bond kept, or the truncbelow cut) are dropped
-        # before the Jacobi sweeps.  Kept singular values then move by at most cut^2 / (2 sigma), i.e. up to
-        # rank_cut^2 / 2 RELATIVE for the smallest kept one.  OFF by default: the north-star parity is 1e-8 relative
-        # on every kept Schmidt value.  Measured at chi = 1024 (energy unchanged to 3e-15 in all cases):
-        #   rank_cut 1e-3: sweep -4 %, smallest kept values to <= 5e-7 relative;  0.05: sweep -16 %, <= 1.3e-3.
-        self.rank_cut = 0.0
-        self._cut_hint = {}
-        self.bonds = [Bond(b) for b in bonds]
-        self._plan_cache = {}
-        self.cache_hits = self.cache_misses = 0
-        self.site_lay = [None] * self.L
-        self.site_buf = [None] * self.L
-        for i in range(self.L):
-            self._upload_site(i, tensors[i], "R")
-        self.Llay = [None] * (self.L + 1)
-        self.Lbuf = [None] * (self.L + 1)
-        self.Rlay = [None] * (self.L + 1)
-        self.Rbuf = [None] * (self.L + 1)
-        # boundaries: an open end (no environment blocks: only the implicit identity level), or -- for a window
-        # inside a larger system (idmrg.py) -- the (EnvLayout, device buffer) of the block beyond that end
-        if left_env is None:
-            self.Llay[0] = EnvLayout.build("L", self.bonds[0], mpo[0].left)
-            self.Lbuf[0] = ops.zeros_z(max(self.Llay[0].size, 1))
-        else:
-            self.Llay[0], self.Lbuf[0] = left_env
-            assert self.Llay[0].bond == self.bonds[0] and self.Llay[0].levels == list(mpo[0].left)
-        if right_env is None:
-            self.Rlay[self.L] = EnvLayout.build("R", self.bonds[self.L], mpo[self.L - 1].right)
-            self.Rbuf[self.L] = ops.zeros_z(max(self.Rlay[self.L].size, 1))
-        else:
-            self.Rlay[self.L], self.Rbuf[self.L] = right_env
-            assert self.Rlay[self.L].bond == self.bonds[self.L] and self.Rlay[self.L].levels == list(mpo[self.L - 1].right)
-        for i in range(self.L - 1, 0, -1):
-            self._right_env(i)
         self.energy = None
         self.stats = []
-        self.spectra = {}
+        L = self.L
+        bond_ptr, secs = [0], []
+        for b in bonds:
+            items = sorted((k, int(v)) for k, v in dict(b).items() if v > 0)
+            secs.extend((N, j, n) for (N, j), n in items)
+            bond_ptr.append(len(secs))
+        sec_arr = np.array(secs, dtype=np.int32).reshape(-1, 3).view(abi.SECTOR_DT).reshape(-1)
+        subs, sub_ptr, data_ptr, chunks, pos = [], [0], [0], [], 0
+        for i in range(L):
+            off = 0
+            for (l, s, r), blk in tensors[i].items():
+                blk = np.asarray(blk, dtype=np.complex128)
+                m, n = blk.shape
+                subs.append((l[0], l[1], s, r[0], r[1], m, off))
+                chunks.append(np.asfortranarray(blk).reshape(-1, order="F"))
+                off += m * n
+            sub_ptr.append(len(subs))
+            pos += off
+            data_ptr.append(pos)
+        sub_arr = np.array(subs, dtype=np.int64).reshape(-1, 7)
+        sb = np.zeros(max(len(subs), 1), dtype=abi.SUBBLOCK_DT)
+        if len(subs):
+            for k, f in enumerate(("lN", "lj", "s", "rN", "rj", "ld", "off")):
+                sb[f] = sub_arr[:, k]
+        data = np.concatenate(chunks) if chunks else np.zeros(1, dtype=np.complex128)
+        bp = np.array(bond_ptr, dtype=np.int32)
+        sp = np.array(sub_ptr, dtype=np.int32)
+        dp = np.array(data_ptr, dtype=np.int64)
+        le = None if left_env is None else np.ascontiguousarray(left_env, dtype=np.complex128)
+        re_ = None if right_env is None else np.ascontiguousarray(right_env, dtype=np.complex128)
+        h = C.c_void_p()
+        abi.check(self.lib, self.lib.htn_mps_create(ops.ctx, self.cmpo.handle, L, bp.ctypes.data, sec_arr.ctypes.data,
+                                                    sp.ctypes.data, sb.ctypes.data, dp.ctypes.data, data.ctypes.data,
+                                                    None if le is None else le.ctypes.data,
+                                                    None if re_ is None else re_.ctypes.data, C.byref(h)),
+                  "htn_mps_create")
+        self.handle = h
 
-    # ---- plan cache --------------------------------------------------------------------------------
-    # Task lists depend only on the sector tables of the bonds involved (and the MPO site), not on the
-    # tensor data, and in converged sweeps the same tables recur bond after bond, sweep after sweep.
-    # Like TensorKit's global fusion-tree-transformer caches, compiled plans (already uploaded) are
-    # memoised by those tables.
-    def _cached(self, key, builder):
-        hit = self._plan_cache.get(key)
-        if hit is None:
-            if len(self._plan_cache) > 20000:
-                self._plan_cache.clear()
-            hit = builder()
-            self._plan_cache[key] = hit
-            self.cache_misses += 1
-        else:
-            self.cache_hits += 1
-        return hit
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.htn_mps_destroy(h)
 
-    def _site_layout(self, kind, bl, br):
-        return self._cached(("slay", kind, bl.key(), br.key()), lambda: SiteLayout.build(kind, bl, br))
+    # ---- options ----------------------------------------------------------------------------------
+    def _opts(self, cutoff=None):
+        o = abi.SweepOpts()
+        o.chi_full = int(self.chi_full) if self.chi_full else 0
+        o.weighting = 0 if self.weighting == "sqrtdim" else 1
+        o.cutoff = float(self.cutoff if cutoff is None else cutoff)
+        o.krylovdim, o.maxrestart, o.lanczos_tol = int(self.krylovdim), int(self.maxrestart), float(self.lanczos_tol)
+        o.jacobi_tol, o.jacobi_max_sweeps = float(self.jacobi_tol), int(self.jacobi_max_sweeps)
+        o.svd_split_elems, o.rank_cut, o.profile = int(self.svd_split), float(self.rank_cut), 1 if self.profile else 0
+        return o
 
-    def _theta_layout(self, bl, br):
-        return self._cached(("tl", bl.key(), br.key()), lambda: ThetaLayout.build(bl, br))
+    # ---- state queries ----------------------------------------------------------------------------
+    @property
+    def bonds(self):
+        return [self.bond(b) for b in range(self.L + 1)]
 
-    # ---- host <-> device site tensors -----------------------------------------------------------
-    def _upload_site(self, i, blocks, kind):
-        lay = self._site_layout(kind, self.bonds[i], self.bonds[i + 1])
-        flat = np.zeros(max(lay.size, 1), dtype=np.complex128)
-        for key, (off, m, n, ld) in lay.blocks.items():
-            blk = blocks.get(key)
-            if blk is None:
-                continue
-            assert blk.shape == (m, n), (key, blk.shape, (m, n))
-            # scatter column-major with leading dimension ld
-            idx = off + np.arange(m)[:, None] + ld * np.arange(n)[None, :]
-            flat[idx] = blk
-        self.site_lay[i] = lay
-        self.site_buf[i] = self.ops.to_device(flat)
+    def bond(self, b) -> Bond:
+        n = self.lib.htn_mps_bond(self.handle, b, None)
+        arr = np.zeros(max(n, 1), dtype=abi.SECTOR_DT)
+        self.lib.htn_mps_bond(self.handle, b, arr.ctypes.data)
+        return Bond({(int(r["N"]), int(r["j"])): int(r["count"]) for r in arr[:n]})
 
-    def download_site(self, i):
-        lay = self.site_lay[i]
-        flat = self.ops.to_host(self.site_buf[i])
-        out = {}
-        for key, (off, m, n, ld) in lay.blocks.items():
-            idx = off + np.arange(m)[:, None] + ld * np.arange(n)[None, :]
-            out[key] = flat[idx].copy()
+    def bond_dims(self):
+        """`dim_state` analogue (src/HubbardFunctions.jl:1399-1405): TensorKit dim of each bond"""
+        return [b.dim_full for b in self.bonds]
+
+    @property
+    def spectra(self):
+        return {b: s for b in range(1, self.L) for s in [self.spectrum(b)] if s}
+
+    def spectrum(self, b):
+        """Schmidt values of the last update of bond b: {sector: descending array}"""
+        n = self.lib.htn_mps_spectrum(self.handle, b, None, None)
+        if n <= 0:
+            return {}
+        secs = np.zeros(n, dtype=abi.SECTOR_DT)
+        vals = np.zeros(n)
+        self.lib.htn_mps_spectrum(self.handle, b, secs.ctypes.data, vals.ctypes.data)
+        out, pos = {}, 0
+        for r in secs:
+            if pos >= n:
+                break
+            c = int(r["count"])
+            out[(int(r["N"]), int(r["j"]))] = vals[pos:pos + c].copy()
+            pos += c
         return out
 
-    def download_env(self, side, i):
-        lay = self.Llay[i] if side == "L" else self.Rlay[i]
-        flat = self.ops.to_host(self.Lbuf[i] if side == "L" else self.Rbuf[i])
-        return {key: flat[off:off + m * n].reshape(n, m).T.copy() for key, (off, m, n) in lay.blocks.items()}
+    def download_site(self, i):
+        """{(l, s, r): ndarray[n_l, n_r]} of site i as stored (left or right layout)"""
+        nb = self.lib.htn_mps_get_site(self.handle, i, None, None)
+        size = self.lib.htn_mps_site_size(self.handle, i, None)
+        subs = np.zeros(max(nb, 1), dtype=abi.SUBBLOCK_DT)
+        flat = np.zeros(max(size, 1), dtype=np.complex128)
+        if self.lib.htn_mps_get_site(self.handle, i, subs.ctypes.data, flat.ctypes.data) < 0:
+            raise abi.HtnError(self.lib.htn_last_error().decode())
+        out = {}
+        for sb in subs[:nb]:
+            l, r = (int(sb["lN"]), int(sb["lj"])), (int(sb["rN"]), int(sb["rj"]))
+            m, n = self.bond_of_site(i, 0)[l], self.bond_of_site(i, 1)[r]
+            idx = int(sb["off"]) + np.arange(m)[:, None] + int(sb["ld"]) * np.arange(n)[None, :]
+            out[(l, int(sb["s"]), r)] = flat[idx].copy()
+        return out
 
-    # ---- environments -----------------------------------------------------------------------------
-    def _bufs(self, **kw):
-        table = [None] * 8
-        for k, v in kw.items():
-            table[{"x": BUF_X, "y": BUF_Y, "l": BUF_L, "r": BUF_R, "z": BUF_Z, "s1": BUF_S1, "s2": BUF_S2,
-                   "aux": BUF_AUX}[k]] = v
-        return table
+    def bond_of_site(self, i, side):
+        key = ("_b", i + side)
+        cache = self.__dict__.setdefault("_bond_cache", {})
+        # bonds change with every update: the cache is dropped in update_bond / sweep
+        if key not in cache:
+            cache[key] = self.bond(i + side)
+        return cache[key]
 
-    def _left_env(self, i):
-        """GL on bond i+1 from GL on bond i and the left-layout tensor of site i"""
-        ops = self.ops
-        lay = self.site_lay[i]
-        assert lay.kind == "L"
+    def site_kind(self, i):
+        k = C.c_int32(0)
+        self.lib.htn_mps_site_size(self.handle, i, C.byref(k))
+        return chr(k.value)
 
-        def build():
-            Lnew = EnvLayout.build("L", self.bonds[i + 1], self.mpo[i].right)
-            t1, t2, zsize = pl.plan_env_cached("L", self.Llay[i], lay, self.mpo[i], Lnew)
-            return Lnew, ops.upload_tasks(t1), ops.upload_tasks(t2), zsize, t1.flops + t2.flops
-        Lnew, d1, d2, zsize, flops = self._cached(("lenv", i, self.bonds[i].key(), self.bonds[i + 1].key()), build)
-        z = ops.empty_z(max(zsize, 1))
-        out = ops.empty_z(max(Lnew.size, 1))
-        ops.grouped_gemm(self._bufs(l=self.Lbuf[i], s1=self.site_buf[i], z=z), d1)
-        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], z=z, y=out), d2)
-        self.Llay[i + 1], self.Lbuf[i + 1] = Lnew, out
-        return flops
+    def env_data(self, side, b):
+        """flat environment (library block order) on bond b; side 'L' / 'R'"""
+        sd = 0 if side == "L" else 1
+        n = self.lib.htn_mps_env_size(self.handle, sd, b)
+        if n < 0:
+            raise abi.HtnError(f"environment {side} of bond {b} does not exist")
+        flat = np.zeros(max(n, 1), dtype=np.complex128)
+        abi.check(self.lib, self.lib.htn_mps_get_env(self.handle, sd, b, flat.ctypes.data), "htn_mps_get_env")
+        return flat[:n]
 
-    def _right_env(self, i):
-        """GR on bond i from GR on bond i+1 and the right-layout tensor of site i"""
-        ops = self.ops
-        lay = self.site_lay[i]
-        assert lay.kind == "R"
+    def download_env(self, side, b):
+        """{(x, w, y): matrix}: left env keys (bra, w, ket) -> [n_bra, n_ket]; right env (ket, w, bra) -> [n_ket, n_bra]"""
+        sd = 0 if side == "L" else 1
+        nb = self.lib.htn_mps_env_blocks(self.handle, sd, b, None)
+        blk = np.zeros(max(nb, 1), dtype=abi.ENV_BLOCK_DT)
+        self.lib.htn_mps_env_blocks(self.handle, sd, b, blk.ctypes.data)
+        flat = self.env_data(side, b)
+        out = {}
+        for r in blk[:nb]:
+            m, n, off = int(r["rows"]), int(r["cols"]), int(r["off"])
+            out[((int(r["aN"]), int(r["aj"])), int(r["w"]), (int(r["bN"]), int(r["bj"])))] = \
+                flat[off:off + m * n].reshape(n, m).T.copy()
+        return out
 
-        def build():
-            Rnew = EnvLayout.build("R", self.bonds[i], self.mpo[i].left)
-            t1, t2, zsize = pl.plan_env_cached("R", self.Rlay[i + 1], lay, self.mpo[i], Rnew)
-            return Rnew, ops.upload_tasks(t1), ops.upload_tasks(t2), zsize, t1.flops + t2.flops
-        Rnew, d1, d2, zsize, flops = self._cached(("renv", i, self.bonds[i].key(), self.bonds[i + 1].key()), build)
-        z = ops.empty_z(max(zsize, 1))
-        out = ops.empty_z(max(Rnew.size, 1))
-        ops.grouped_gemm(self._bufs(r=self.Rbuf[i + 1], s1=self.site_buf[i], z=z), d1)
-        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], z=z, y=out), d2)
-        self.Rlay[i], self.Rbuf[i] = Rnew, out
-        return flops
+    def theta(self, i):
+        n = self.lib.htn_mps_theta_size(self.handle, i)
+        out = np.zeros(n, dtype=np.complex128)
+        abi.check(self.lib, self.lib.htn_mps_get_theta(self.handle, i, out.ctypes.data), "htn_mps_get_theta")
+        return out
 
-    # ---- effective Hamiltonian --------------------------------------------------------------------
-    def _make_apply(self, i, tl):
-        """stage list of the H_eff apply on bond (i, i+1): [(buffer table, device task list), ...]"""
-        ops = self.ops
+    def apply_heff(self, i, x):
+        """y = H_eff(bond i, i+1) x on host vectors in the library's theta layout"""
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        n = self.lib.htn_mps_theta_size(self.handle, i)
+        assert x.shape == (n,)
+        y = np.zeros(n, dtype=np.complex128)
+        abi.check(self.lib, self.lib.htn_heff2_apply(self.handle, i, x.ctypes.data, y.ctypes.data), "htn_heff2_apply")
+        return y
 
-        def build():
-            tz, ty, zsize, nterms = pl.plan_apply_cached(tl, self.Llay[i], self.Rlay[i + 2], self.mpo[i], self.mpo[i + 1])
-            flops = ty.flops + (tz.flops if tz is not None else 0)
-            ntiles = ty.ntiles + (tz.ntiles if tz else 0)
-            nsegs = ty.nsegs + (tz.nsegs if tz else 0)
-            if self.shard is not None:
-                rank, world, _ = self.shard
-                ty = _shard_tasks(ty, rank, world)
-            return (ops.upload_tasks(tz) if tz is not None else None, ops.upload_tasks(ty), zsize, flops, ntiles, nsegs)
-        dz, dy, zsize, flops, ntiles, nsegs = self._cached(
-            ("apply", i, self.bonds[i].key(), self.bonds[i + 2].key()), build)
-        z = ops.empty_z(max(zsize, 1))
-        Lb, Rb = self.Lbuf[i], self.Rbuf[i + 2]
-        stages = []
-        if dz is not None:
-            stages.append((self._bufs(l=Lb, z=z), dz))
-        stages.append((self._bufs(l=Lb, r=Rb, z=z), dy))
-        nbytes = 16 * (2 * tl.size + self.Llay[i].size + self.Rlay[i + 2].size)
-        return stages, flops, nbytes, ntiles, nsegs
+    def plan_apply_dump(self, i, stage):
+        """(tiles, segs, z_size, flops) of the H_eff apply on bond i as the kernels receive them (tests)"""
+        nt, nsg, zs, fl = C.c_int32(0), C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        abi.check(self.lib, self.lib.htn_plan_apply_dump(self.handle, i, stage, C.byref(nt), None, C.byref(nsg), None,
+                                                         C.byref(zs), C.byref(fl)), "htn_plan_apply_dump")
+        tiles = np.zeros(max(nt.value, 1), dtype=abi.TILE_DT)
+        segs = np.zeros(max(nsg.value, 1), dtype=abi.SEG_DT)
+        abi.check(self.lib, self.lib.htn_plan_apply_dump(self.handle, i, stage, C.byref(nt), tiles.ctypes.data,
+                                                         C.byref(nsg), segs.ctypes.data, C.byref(zs), C.byref(fl)),
+                  "htn_plan_apply_dump")
+        return tiles[:nt.value], segs[:nsg.value], zs.value, fl.value
 
-    # ---- one bond ---------------------------------------------------------------------------------
-    def update_bond(self, i, direction, placement, optimise=True):
-        """optimise sites (i, i+1); placement 'right': A_i = U, centre S V^H on i+1 (+ left env);
-        'left': centre U S on i, B_{i+1} = V^H (+ right env).  optimise=False only moves the centre: the
-        eigensolver stops after its first step (x = theta normalised, E = <theta|H|theta>)."""
-        t0 = time.perf_counter()
-        ops = self.ops
-        bl, br = self.bonds[i], self.bonds[i + 2]
-        tl = self._theta_layout(bl, br)
-        n = tl.size
-        kd = self.krylovdim
-        lay1, lay2 = self.site_lay[i], self.site_lay[i + 1]
-        mode = lay1.kind + lay2.kind
-        assert mode in ("RR", "LL", "LR"), mode
-        V = ops.empty_z((kd + 2) * n)
-        # theta -> V[0] (the Lanczos driver normalises it)
-        dth = self._cached(("theta", mode, bl.key(), self.bonds[i + 1].key(), br.key()),
-                           lambda: ops.upload_tasks(pl.plan_theta(mode, lay1, lay2, tl)))
-        ops.grouped_gemm(self._bufs(s1=self.site_buf[i], s2=self.site_buf[i + 1], y=V[0:n]), dth)
-        stages, aflops, abytes, ntiles, nsegs = self._make_apply(i, tl)
-        if self.profile:
-            ops.sync()
-        t_plan = time.perf_counter() - t0
-        E, nmv, res = ops.lanczos(stages, BUF_X, BUF_Y, V, n, kd, self.lanczos_tol if optimise else 1e300, self.maxrestart,
-                                  zero_y=self.shard is not None,
-                                  exchange=self.shard[2] if self.shard is not None else None)
-        if self.profile:
-            ops.sync()
-        t_lan = time.perf_counter() - t0 - t_plan
-        x = V[0:n]
-        # ---- SVD + truncation ----
-        sp, d_stage, d_desc = self._cached(("svd", placement, bl.key(), br.key()),
-                                           lambda: (lambda p_: (p_, ops.to_device(p_.stage), ops.to_device(p_.desc)))(
-                                               pl.plan_svd(tl, placement)))
-        nb = len(sp.mids)
-        G = ops.empty_z(max(sp.g_size, 1))
-        Vj = ops.empty_z(max(sp.v_size, 1))
-        S = ops.empty_f64(max(sp.s_size, 1))
-        info = ops.empty_i32(max(nb, 1))
-        ops.batched_copy(G, x, None, None, d_stage, nb, 1.0)
-        # Singular directions far below what the truncation keeps need not be resolved.  truncbelow(eta): everything
-        # below eta goes anyway.  truncdim(D): if the previous update of this bond (same D) was limited by D, its
-        # smallest kept value is where the cut will fall again.  x is normalised, so values compare across sweeps.
-        cut = 0.0
-        set_cut = getattr(ops, "jacobi_set_rank_cut", None)
-        if set_cut is not None and self.rank_cut > 0.0:
-            hint = self._cut_hint.get(i + 1)
-            if hint is not None and hint[0] == (self.chi_full, self.cutoff):
-                cut = self.rank_cut * hint[1]
-            cut = max(cut, self.rank_cut * self.cutoff)
-        if cut > 0.0:
-            set_cut(cut)
-        try:
-            ops.jacobi_svd(G, Vj, S, d_desc, nb, sp.max_m, self.jacobi_max_sweeps, self.jacobi_tol, info,
-                           desc_host=sp.desc)
-        finally:
-            if cut > 0.0:
-                set_cut(0.0)
-        s_host = ops.to_host(S)
-        info_h = ops.to_host(info)
-        if nb and int(info_h[:nb].min()) < 0:
-            raise RuntimeError("Jacobi SVD did not converge")
-        # per-block descending order and the global truncation on flat arrays (one lexsort instead of a Python loop
-        # over the blocks; the sector numbering of sp.mids is the sorted label order truncate() uses)
-        st_ = sp.__dict__.get("_flat")
-        if st_ is None:
-            offs = sp.desc["s_off"][:nb].astype(np.int64)
-            lens = sp.desc["n"][:nb].astype(np.int64)
-            assert list(sp.mids) == sorted(sp.mids) and np.array_equal(offs, np.cumsum(lens) - lens)
-            sid = np.repeat(np.arange(nb), lens)
-            st_ = sp.__dict__["_flat"] = (offs, lens, sid, np.arange(int(lens.sum())) - np.repeat(offs, lens),
-                                          np.array([c[1] + 1 for c in sp.mids], dtype=np.int64)[sid])
-        offs, lens, sid, pos, dims = st_
-        sv = s_host[:len(sid)]
-        perm = np.lexsort((pos, -sv, sid))                    # by block, value descending, original index ascending
-        vals = sv[perm]
-        counts, tw, nrm = pl.truncate_arrays(vals, sid, pos, dims, nb, self.chi_full, self.cutoff, self.weighting)
-        local = perm - np.repeat(offs, lens)                  # column index inside its block
-        svals = {c: vals[offs[k]:offs[k] + lens[k]] for k, c in enumerate(sp.mids)}
-        order = {c: local[offs[k]:offs[k] + lens[k]] for k, c in enumerate(sp.mids)}
-        keep = {c: int(counts[k]) for k, c in enumerate(sp.mids)}
-        mid = Bond({c: k for c, k in keep.items() if k > 0})
-        # hint for the next visit of this bond: the smallest kept value, valid only if the dimension limit (not the
-        # number of available states) ended the kept set
-        kept_tot = int(counts.sum())
-        if self.chi_full is not None and tw > 0.0 and kept_tot > 0 and kept_tot < int((vals > 0.0).sum()):
-            ends = offs + np.maximum(counts, 1) - 1
-            self._cut_hint[i + 1] = ((self.chi_full, self.cutoff), float(vals[ends][counts > 0].min()))
-        else:
-            self._cut_hint.pop(i + 1, None)
-        # the finalisation plan depends on the kept COUNTS only (not on which columns carry them): in converged sweeps
-        # the same counts recur at the same bond, so layouts, copy items and the centre GEMM list (already on the
-        # device) are memoised; only the column indices travel per update
-        def build_fin():
-            layA_ = self._site_layout("L", bl, mid)
-            layB_ = self._site_layout("R", mid, br)
-            ident = {c: np.arange(int(lens[k])) for k, c in enumerate(sp.mids)}        # placeholder order: idx only
-            ig, cg, iv, _, cen = pl.plan_finalize(tl, sp, ident, keep, layA_, layB_, placement, 0, layA_.size)
-            ig_d, cg_d, iv_d = ops.to_device_packed([ig, cg, iv])
-            return (layA_, layB_, ig_d, len(ig), cg_d, len(cg), iv_d, len(iv),
-                    ops.upload_tasks(cen) if cen is not None else None)
-        layA, layB, iso_g_d, n_ig, cen_g_d, n_cg, iso_v_d, n_iv, cen_dev = self._cached(
-            ("fin", placement, bl.key(), br.key(), counts.tobytes()), build_fin)
-        offA, offB = 0, layA.size
-        idx = np.concatenate([order[c][:keep[c]] for c in sp.mids if keep[c] > 0]).astype(np.int32) if kept_tot else \
-            np.zeros(1, dtype=np.int32)
-        out = ops.zeros_z(max(layA.size + layB.size, 1))
-        idx_d = ops.to_device(idx)
-        if n_ig:
-            ops.batched_copy(out, G, idx_d, S, iso_g_d, n_ig, 1.0)
-        if n_cg:
-            ops.batched_copy(out, G, idx_d, S, cen_g_d, n_cg, 1.0 / nrm)
-        if n_iv:
-            ops.batched_copy(out, Vj, idx_d, S, iso_v_d, n_iv, 1.0)
-        if cen_dev is not None:
-            ops.scale_inplace(x, 1.0 / nrm)                      # centre = U^H (M / nrm)
-            ops.grouped_gemm(self._bufs(x=x, s1=out, y=out), cen_dev)
-        bufA, bufB = out[offA:offA + max(layA.size, 1)], out[offB:offB + max(layB.size, 1)]
-        self.bonds[i + 1] = mid
-        self.site_lay[i], self.site_buf[i] = layA, bufA
-        self.site_lay[i + 1], self.site_buf[i + 1] = layB, bufB
-        if self.profile:
-            ops.sync()
-        t_svd = time.perf_counter() - t0 - t_plan - t_lan
-        if placement == "right":
-            self._left_env(i)
-        else:
-            self._right_env(i + 1)
-        if self.profile:
-            ops.sync()
-        t_env = time.perf_counter() - t0 - t_plan - t_lan - t_svd
-        self.energy = E
-        self.spectra[i + 1] = {c: svals[c][:keep[c]] / nrm / np.sqrt(c[1] + 1) for c in svals if keep[c] > 0}
-        st = BondStats(bond=i + 1, direction=direction, energy=E, n_matvec=nmv, residual=res, trunc_weight=tw,
-                       chi_full=mid.dim_full, multiplets=mid.multiplets, theta_size=n, apply_flops=aflops,
-                       apply_bytes=abytes, svd_flops=sp.flops,
-                       jacobi_sweeps=int(info_h[:nb].max()) if nb else 0, n_tiles=ntiles, n_segs=nsegs,
-                       t_plan=t_plan, t_total=time.perf_counter() - t0, t_lanczos=t_lan, t_svd=t_svd,
-                       t_env=t_env)
-        self.stats.append(st)
-        return E
+    @property
+    def cache_hits(self):
+        return self._cache_stats()[0]
+
+    @property
+    def cache_misses(self):
+        return self._cache_stats()[1]
+
+    def _cache_stats(self):
+        h, m = C.c_int64(0), C.c_int64(0)
+        self.lib.htn_mps_cache_stats(self.handle, C.byref(h), C.byref(m))
+        return h.value, m.value
+
+    # ---- updates ----------------------------------------------------------------------------------
+    def update_bond(self, i, direction, placement, optimise=True, record=True, cutoff=None):
+        """optimise sites (i, i+1); placement 'right': A_i = U, centre S V^H on i+1 (+ left env); 'left': centre U S on
+        i, B_{i+1} = V^H (+ right env).  optimise=False only moves the centre (E = <theta|H|theta>)."""
+        self.__dict__.pop("_bond_cache", None)
+        st = np.zeros(1, dtype=abi.BOND_STATS_DT)
+        o = self._opts(cutoff)
+        abi.check(self.lib, self.lib.htn_bond_update(self.handle, i, direction, 0 if placement == "right" else 1,
+                                                     1 if optimise else 0, C.byref(o), st.ctypes.data), "htn_bond_update")
+        s = _stats(st[0])
+        if record:
+            self.stats.append(s)
+            self.energy = s.energy
+        return s.energy
 
     def sweep(self):
-        """one sweep in MPSKit's DMRG2 order: bonds 0..L-2 rightwards, L-3..0 leftwards."""
-        L = self.L
-        for i in range(L - 1):
-            self.update_bond(i, +1, "right" if i < L - 2 else "left")
-        for i in range(L - 3, -1, -1):
-            self.update_bond(i, -1, "left")
+        """one sweep in MPSKit's DMRG2 order (bonds 0..L-2 rightwards, L-3..0 leftwards), one library call"""
+        self.__dict__.pop("_bond_cache", None)
+        n = 2 * self.L - 3
+        st = np.zeros(n, dtype=abi.BOND_STATS_DT)
+        E = C.c_double(0.0)
+        o = self._opts()
+        abi.check(self.lib, self.lib.htn_dmrg2_sweep(self.handle, C.byref(o), st.ctypes.data, C.byref(E)), "htn_dmrg2_sweep")
+        self.stats.extend(_stats(r) for r in st)
+        self.energy = E.value
         return self.energy
 
     def site_occupations(self):
         """-> (n, d): <n_i> and the double occupancy <n_up n_dn>_i of every site (density_state, src:1495-1523).
         Call after sweep() (centre on site 0, sites >= 1 right-canonical).  The centre is carried through the chain
         without optimisation; with the centre on site i the probability of site multiplet s is the squared norm
-        of the (., s, .) blocks (tilde normalisation), and n = P(single) + 2 P(double)."""
+        of the (., s, .) blocks (tilde normalisation), and n = P(single) + 2 P(double).  Leaves stats/energy alone."""
         L = self.L
         n, d = np.zeros(L), np.zeros(L)
 
@@ -392,41 +350,63 @@ class DMRG2:
                 p[s] += float(np.sum(np.abs(blk) ** 2))
             p /= p.sum()
             n[i], d[i] = p[1] + 2.0 * p[2], p[2]
-        saved = (self.chi_full, self.cutoff, self.stats, self.energy, dict(self.spectra))
-        self.cutoff = 0.0                                       # moving the centre must not truncate by value
         read(0)
-        for i in range(L - 1):
-            self.update_bond(i, +1, "right", optimise=False)
+        for i in range(L - 1):          # moving the centre must not truncate by value: cutoff 0
+            self.update_bond(i, +1, "right", optimise=False, record=False, cutoff=0.0)
             read(i + 1)
-        for i in range(L - 2, -1, -1):                          # back to the post-sweep convention
-            self.update_bond(i, -1, "left", optimise=False)
-        self.chi_full, self.cutoff, self.stats, self.energy, self.spectra = saved
+        for i in range(L - 2, -1, -1):  # back to the post-sweep convention
+            self.update_bond(i, -1, "left", optimise=False, record=False, cutoff=0.0)
         return n, d
+
+    def bond_energies(self):
+        """<psi| H |psi> of the state AS STORED (truncated), evaluated by a non-optimising pass: returns (E_total,
+        per-bond running values).  Call after sweep() (centre on site 0).  The expectation value is the same number at
+        every bond (the centre move is exact when nothing is truncated: cutoff 0, and the dimension limit is not
+        reached by a state that already obeys it); the list documents that."""
+        vals = []
+        for i in range(self.L - 1):
+            vals.append(self.update_bond(i, +1, "right" if i < self.L - 2 else "left", optimise=False, record=False,
+                                         cutoff=0.0))
+        for i in range(self.L - 3, -1, -1):
+            vals.append(self.update_bond(i, -1, "left", optimise=False, record=False, cutoff=0.0))
+        return vals[-1], vals
 
     def svd_cut(self, chi_full):
         """truncate every bond to truncdim(chi_full) by SVD alone (MPSKit `changebonds(psi, SvdCut(trscheme))`,
-        used at src:1363-1365): one pass of centre moves without optimisation at the new limit.  Returns the
-        energy <psi|H|psi> of the truncated state.  Call after sweep()."""
-        saved = (self.cutoff, self.stats)
-        self.chi_full, self.cutoff = int(chi_full), 0.0
+        used at src:1363-1365): one pass of centre moves without optimisation at the new limit, then a second,
+        non-truncating pass that evaluates <psi|H|psi> of the TRUNCATED state, which is returned.  Call after sweep()."""
+        self.chi_full = int(chi_full)
         for i in range(self.L - 1):
-            self.update_bond(i, +1, "right" if i < self.L - 2 else "left", optimise=False)
+            self.update_bond(i, +1, "right" if i < self.L - 2 else "left", optimise=False, record=False, cutoff=0.0)
         for i in range(self.L - 3, -1, -1):
-            self.update_bond(i, -1, "left", optimise=False)
-        self.cutoff, self.stats = saved
-        return self.energy
+            self.update_bond(i, -1, "left", optimise=False, record=False, cutoff=0.0)
+        E, _ = self.bond_energies()
+        self.energy = E
+        return E
 
-    def bond_dims(self):
-        """`dim_state` analogue (src/HubbardFunctions.jl:1399-1405): TensorKit dim of each bond"""
-        return [b.dim_full for b in self.bonds]
-
-
-def _shard_tasks(tasks, rank, world):
-    """owner-computes split of the output tiles over ranks: tiles are sorted by work (LPT order),
-    dealing them round-robin balances MACs; every rank keeps the full segment table."""
-    import copy
-    t = copy.copy(tasks)
-    sel = np.arange(tasks.ntiles)[rank::world]
-    t.tiles = np.ascontiguousarray(tasks.tiles[sel]) if len(sel) else tasks.tiles[:1].copy()
-    t.ntiles = len(sel)
-    return t
+    def site_energies(self):
+        """genuine <psi|H|psi> of the state as stored, split per site: e_i = energy of all Hamiltonian terms that END
+        on site i (on-site terms of i, and every two-site term whose right-most site is i); sum(e) = <psi|H|psi>.
+        Evaluated by one non-optimising rightward pass: with the centre in Schmidt form on bond b, the completed-term
+        level of the left environment gives E(sites < b) = sum_c sum_k s~_{c,k}^2 GL_final[c][k, k]; the last site closes
+        with the total <theta|H|theta>.  Call after sweep() (centre on site 0); the state is left as found."""
+        L = self.L
+        run = np.zeros(L)                                   # run[i] = energy of the terms inside sites 0..i
+        E_tot = None
+        nfin = len(self.mpo[0].right) - 1
+        for i in range(L - 1):
+            E_tot = self.update_bond(i, +1, "right", optimise=False, record=False, cutoff=0.0)
+            spec = self.spectrum(i + 1)
+            env = self.download_env("L", i + 1)
+            wfin = len(self.mpo[i].right) - 1               # 'term complete' level of the MPO bond right of site i
+            acc = 0.0
+            for (bra, w, ket), M in env.items():
+                if w == wfin and bra == ket and bra in spec:
+                    s2 = (bra[1] + 1) * np.asarray(spec[bra]) ** 2
+                    acc += float(np.real(np.sum(np.diag(M)[:len(s2)] * s2)))
+            run[i] = acc
+        run[L - 1] = E_tot
+        for i in range(L - 2, -1, -1):                      # back to the post-sweep convention (centre on site 0)
+            self.update_bond(i, -1, "left", optimise=False, record=False, cutoff=0.0)
+        e = np.diff(np.concatenate([[0.0], run]))
+        return e

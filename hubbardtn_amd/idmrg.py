@@ -11,11 +11,11 @@ McCulloch's original formulation, which needs nothing but the finite-chain engin
 
 Every step adds 2 T sites, so  e = (E_n - E_{n-1}) / (2 T)  is the energy per site and the change of the centre
 Schmidt spectrum is the convergence measure (the ||dC|| of MPSKit; C is diagonal after the SVD).  All arithmetic
-is the finite sweep's: H_eff apply, Lanczos, per-sector SVD, environment transfer -- the HIP hot path.
+is the finite sweep's: H_eff apply, Lanczos, per-sector SVD, environment transfer -- the library's hot path.
 
 Sector labels stay absolute (N = particles to the left of the bond): the left block's labels simply grow; the
 right block's environment is re-keyed by the window's particle content 2 T P/Q when a window is inserted in front
-of it (sorted block order, hence the device buffer, is invariant under that shift).  The reference's shifted charge
+of it (sorted block order, hence the flat buffer, is invariant under that shift).  The reference's shifted charge
 k = N Q - P sites (src:251) is this relabelling done once and for all.
 """
 from __future__ import annotations
@@ -26,20 +26,11 @@ import numpy as np
 
 from . import engine as _engine
 from . import models, mps
-from .planner import Bond, EnvLayout
 
 
 def unit_cell(P: int, Q: int) -> int:
     """T = Q if P even else 2 Q (src:408-412)"""
     return Q if P % 2 == 0 else 2 * Q
-
-
-def _shift_right_env(Rlay: EnvLayout, dN: int) -> EnvLayout:
-    """the same environment, its bond relabelled N -> N + dN"""
-    new = EnvLayout.build("R", Bond({(N + dN, j): n for (N, j), n in Rlay.bond.dims.items()}), Rlay.levels)
-    old = list(Rlay.blocks.values())
-    assert new.size == Rlay.size and list(new.blocks.values()) == old, "relabelling must keep the block order"
-    return new
 
 
 def _spectrum_distance(a: dict, b: dict, dN: int) -> float:
@@ -66,6 +57,7 @@ class IDMRGResult:
     spectrum: dict               # centre Schmidt spectrum {sector: values} (absolute labels of the last window)
     history: list = field(default_factory=list)     # (energy per site, delta) per growth step
     engine: object = None        # the last window's engine (device-resident tensors of two unit cells)
+    boundary: dict = field(default_factory=dict)    # bL, bR, Lenv, Renv of the last window (what storage needs to re-create it)
 
 
 def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_per_step=6, init_dimension=8,
@@ -82,23 +74,24 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
     ncells = 8 * unit_cell(P, Q)
     big = models.hamiltonian(sim, ncells)
     m0 = 3 * T
-    mpo = [big[m0 + i] for i in range(W)]
+    sites = [big[m0 + i] for i in range(W)]
     key = lambda w: (tuple(w.left), tuple(w.right), tuple(w.entries))
     assert key(big[m0]) == key(big[m0 + T]) == key(big[m0 + W]), "MPO is not periodic with the unit cell"
-    # step 0: the window alone, open ends
+    cmpo = _engine.CMpo(ops, sites)
+    # step 0: the window alone.  Its MPO bonds are the bulk's (full width), so "open ends" are explicit boundary
+    # environments: an empty chain to the left (only the implicit identity level is non-zero) and to the right
     bL = {(0, 0): 1}
     bR = {(dNw, 0): 1}
-    Llay = EnvLayout.build("L", Bond(bL), mpo[0].left)
-    Rlay = EnvLayout.build("R", Bond(bR), mpo[W - 1].right)
-    Lbuf = ops.zeros_z(max(Llay.size, 1))
-    Rbuf = ops.zeros_z(max(Rlay.size, 1))
+    Lenv = _zero_env(bL, sites[0].left, "L")
+    Renv = _zero_env(bR, sites[W - 1].right, "R")
     E_prev, spec_prev, e_site, delta = None, None, float("nan"), float("inf")
     history = []
     eng = None
     for it in range(maxiter):
-        bonds, tensors = mps.random_window(W, Llay.bond.dims, Rlay.bond.dims, init_dimension, seed=seed + it)
-        eng = _engine.DMRG2(ops, mpo, bonds, tensors, chi_full=chi_full, cutoff=cutoff, krylovdim=krylovdim,
-                            lanczos_tol=lanczos_tol, left_env=(Llay, Lbuf), right_env=(Rlay, Rbuf))
+        bonds, tensors = mps.random_window(W, bL, bR, init_dimension, seed=seed + it)
+        eng = _engine.DMRG2(ops, cmpo, bonds, tensors, chi_full=chi_full, cutoff=cutoff, krylovdim=krylovdim,
+                            lanczos_tol=lanczos_tol, left_env=Lenv, right_env=Renv)
+        boundary = {"bL": dict(bL), "bR": dict(bR), "Lenv": Lenv, "Renv": Renv}
         # the window starts from a random state: sweep until its energy has settled (at least twice, at most
         # sweeps_per_step times); a window that has not found its ground state poisons the blocks it is absorbed into
         E_sw = None
@@ -107,22 +100,42 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
             if k >= 1 and E_sw is not None and abs(E_new - E_sw) <= 1e-11 * max(abs(E_new), 1.0):
                 break
             E_sw = E_new
-        # the leftward pass visited the centre bond last: its eigenvalue is the energy of system_n
-        centre = [s for s in eng.stats if s.bond == T][-1]
-        E = centre.energy
-        spec = eng.spectra[T]
+        # energy of system_n: <psi|H|psi> of the window state AS STORED (after the truncations of the last sweep),
+        # evaluated at bond 0 without moving the centre -- not the pre-truncation Ritz value of an eigensolve, which is
+        # biased low by the discarded weight (visible at the reference's truncbelow(1e-2))
+        E = eng.update_bond(0, +1, "left", optimise=False, record=False, cutoff=0.0)
+        spec = eng.spectrum(T)
         if E_prev is not None:
             e_site = (E - E_prev) / W
             delta = _spectrum_distance(spec_prev, spec, dNw // 2)
         history.append((e_site, delta))
         if verbosity:
             print(f"IDMRG2 step {it + 1}: sites {W * (it + 1)}  E/site = {e_site:.10f}  delta = {delta:.3e}  "
-                  f"chi = {eng.bonds[T].dim_full}")
+                  f"chi = {eng.bond(T).dim_full}")
         E_prev, spec_prev = E, spec
         if it + 1 >= min_steps and delta < tol:
             break
-        # absorb the halves: environments at the centre bond become the new boundaries
-        Llay, Lbuf = eng.Llay[T], eng.Lbuf[T]
-        Rlay, Rbuf = _shift_right_env(eng.Rlay[T], dNw), eng.Rbuf[T]
+        # absorb the halves: environments at the centre bond become the new boundaries; the right block's bond is
+        # relabelled N -> N + dNw (block order, hence the flat data, unchanged)
+        mid = eng.bond(T).dims
+        Lenv, Renv = eng.env_data("L", T), eng.env_data("R", T)
+        bL = dict(mid)
+        bR = {(N + dNw, j): n for (N, j), n in mid.items()}
     return IDMRGResult(energy_per_site=e_site, delta=delta, iterations=len(history), unit_cell=T,
-                       bond_dims=[b.dim_full for b in eng.bonds], spectrum=spec_prev, history=history, engine=eng)
+                       bond_dims=eng.bond_dims(), spectrum=spec_prev, history=history, engine=eng, boundary=boundary)
+
+
+def _zero_env(bond: dict, levels, side: str) -> np.ndarray:
+    """environment of an EMPTY block beyond an open end, for a full-width MPO bond: every explicit level is zero
+    (the identity level -- 'nothing applied yet' on the left, 'complete' on the right -- is implicit).  Size = sum over
+    non-identity levels and connected (ket, bra) pairs of n_bra n_ket; for the one-sector boundary bonds used here:"""
+    ident = 0 if side == "L" else len(levels) - 1
+    size = 0
+    for w, (dN, k) in enumerate(levels):
+        if w == ident:
+            continue
+        for ket, nk in bond.items():
+            for bra, nb in bond.items():
+                if bra[0] == ket[0] + dN and abs(ket[1] - k) <= bra[1] <= ket[1] + k and (ket[1] + k + bra[1]) % 2 == 0:
+                    size += nb * nk
+    return np.zeros(max(size, 1), dtype=np.complex128)

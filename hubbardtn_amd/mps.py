@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .planner import full_bonds, fuse, split
+from .sectors import full_bonds, fuse, split
 
 
 def random_mps(nsites, target, max_dimension, seed=1234, max_twoS=6):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HTN_ABI_VERSION 1
+#define HTN_ABI_VERSION 2
 #define HTN_MAX_BUFS 8
 #define HTN_TILE 32              /* output tile edge of the grouped GEMM */
 
@@ -111,11 +111,11 @@ typedef struct {
     int32_t n_tiles;
     int32_t pad;
 } htn_gemm_launch;
-typedef void (*htn_exchange_fn)(void* y_dev, int64_t n, void* user);
+typedef int (*htn_exchange2_fn)(void* y_dev, int64_t n, void* user);    /* != 0: failure, the solve is aborted */
 int64_t htn_lanczos_scratch_elems(int32_t krylovdim);
 int htn_lanczos_z(const htn_gemm_launch* stages_host, int32_t n_stages, int32_t x_slot, int32_t y_slot,
                   void* V, int64_t n, int32_t krylovdim, double tol, int32_t max_restart, void* scratch,
-                  int32_t zero_y, htn_exchange_fn exchange, void* user,
+                  int32_t zero_y, htn_exchange2_fn exchange, void* user,
                   double* eig_host, int32_t* n_matvec_host, double* residual_host,
                   double* matvec_ms_host /* NULL, or receives the HIP-event time of all matvec launches */,
                   void* stream);
@@ -145,23 +145,26 @@ typedef struct {
     int32_t m, n;
     int32_t flags, pad;
 } htn_svd_block;        /* 40 bytes */
+/* Per-call options of htn_jacobi_svd_z (NULL = defaults); replaces the process-wide setters of ABI version 1 so
+ * that two contexts on two host threads cannot see each other's settings.
+ *   split_elems : blocks whose R^H (roundup(m) x n elements) exceeds it leave the one-workgroup kernel for the
+ *                 large-block path (k_qr_large: panel-blocked pivoted QR; k_jacobi_pairs_gram: block Jacobi over many
+ *                 CUs).  <= 0: the default ("does not fit one CU's LDS window", 9216 elements); larger values are
+ *                 clamped to it.  Exists so that small problems can exercise the large-block path (tests); results
+ *                 agree to the Jacobi tolerance either way.
+ *   rank_cut    : rank-revealing stop of the large blocks' pivoted QR: once the squared Frobenius norm of the part
+ *                 not yet factorised is below rank_cut^2 (it bounds every remaining singular value), the remaining
+ *                 rows of R are dropped, the tournament runs on the rank found, and the dropped singular values are
+ *                 reported as 0.  <= 0 = off (default).  Kept singular values then move by at most
+ *                 rank_cut^2 / (2 sigma) (interlacing). */
+typedef struct {
+    int32_t split_elems;
+    int32_t pad;
+    double rank_cut;
+} htn_svd_opts;
 int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc, const htn_svd_block* desc_host,
                      int32_t n_blocks, int32_t max_m_host, int32_t max_sweeps, double tol, int32_t* info_dev,
-                     void* stream);
-
-/* Blocks whose R^H (roundup(m) x n elements) exceeds `elems` leave the one-workgroup kernel for the large-block
- * path (k_qr_large: panel-blocked pivoted QR; k_jacobi_pairs_gram: block Jacobi over many CUs).  elems <= 0 restores
- * the default ("does not fit one CU's LDS window", 9216 elements); values above the default are clamped to it.
- * Returns the previous setting.  Exists so that small problems can exercise the large-block path (tests); results
- * agree to the Jacobi tolerance either way.  Process-wide, not thread safe. */
-int32_t htn_jacobi_set_split(int32_t elems);
-
-/* Rank-revealing stop of the large blocks' pivoted QR: once the squared Frobenius norm of the part not yet
- * factorised is below abs_cut^2 (it bounds every remaining singular value), the remaining rows of R are dropped, the
- * Jacobi tournament runs on the rank found, and the dropped singular values are reported as 0.  abs_cut <= 0 = off
- * (default).  A caller that truncates anyway (truncdim / truncbelow) passes a small fraction of its cut: kept singular
- * values then move by at most abs_cut^2 / (2 sigma) (interlacing).  Returns the previous setting.  Process-wide. */
-double htn_jacobi_set_rank_cut(double abs_cut);
+                     const htn_svd_opts* opts, void* stream);
 
 /* dst(r x c, ldd) = op(src)(.., lds) with optional per-row / per-column real scaling:
  * generic batched strided copy used to (a) stage M or M^H into the Jacobi workspace and
@@ -182,6 +185,185 @@ typedef struct {
 int htn_batched_copy_z(void* dst, const void* src, const int32_t* idx, const double* scl,
                        const htn_copy_item* items, int32_t n_items, double global_scale,
                        void* stream);
+
+
+/* =====================================================================================================
+ * Bond-update / sweep level (ABI 2): what sits behind
+ *     find_groundstate(psi0, H, IDMRG2(; trscheme, tol))          src/HubbardFunctions.jl:1010
+ * i.e. MPSKit's two-site sweep body.  The Hamiltonian builder
+ * (hamiltonian(), src:386-472, 811-910) and initialize_mps (src:917-959) stay on the host-language side, exactly as
+ * in the reference; they hand over
+ *   - the MPO as tables: per site the (dN, 2k) labels of its left / right virtual levels and a list of
+ *     (left level, right level, site-operator id, coefficient) entries; site operators as reduced matrix elements;
+ *   - the MPS as TensorKit-shaped data: one flat ComplexF64 vector per site + a table of sub-blocks
+ *     (left sector, site multiplet, right sector, offset, leading dimension) -- TensorKit's per-fusion-tree views --
+ *     and per bond the int32 sector labels (N, 2S) with their int64... (here int32) multiplet counts.
+ * Everything below that -- sector layouts, recoupling coefficients (closed-form 9j), task lists, theta formation,
+ * Lanczos, per-sector SVD, the global truncation rule, write-back, environment transfer, the sweep loop -- runs
+ * inside the library (C++ planner + HIP kernels; one host thread per context).
+ * Host pointers end in _host; everything is copied at the call, the caller keeps ownership of its buffers.
+ * ===================================================================================================== */
+typedef struct htn_ctx htn_ctx;
+typedef struct htn_mpo htn_mpo;
+typedef struct htn_mps htn_mps;
+
+/* Symmetry of the reduced tensors (src:245-382).  Sector label = (N, j):
+ *   HTN_SYM_SU2_U1 : fZ2 x SU(2) x U(1) (src:250): N = particle number (parity = N mod 2), j = 2S, spins couple
+ *   HTN_SYM_U1_U1  : fZ2 x U(1) x U(1)  (src:247): N = particle number, j = 2 Sz (additive, may be negative)
+ *   HTN_SYM_SU2    : fZ2 x SU(2)        (src:341): N = parity (mod 2), j = 2S
+ * site_N / site_j: labels of the n_site site multiplets (3 or 4). */
+#define HTN_SYM_SU2_U1 0
+#define HTN_SYM_U1_U1 1
+#define HTN_SYM_SU2 2
+#define HTN_MAX_SITE 4
+typedef struct {
+    int32_t kind;
+    int32_t n_site;
+    int32_t site_N[HTN_MAX_SITE];
+    int32_t site_j[HTN_MAX_SITE];
+} htn_symmetry;
+
+/* reduced site operator: irreducible tensor of rank k/2 (SU(2) kinds; U1_U1: k = change of 2Sz) changing N by dN;
+ * red[out * HTN_MAX_SITE + in] = reduced matrix element <out || O || in> in the convention of src:281-293
+ * (isometric fusion tensors: c+ has 1 and sqrt(2)). */
+typedef struct {
+    int32_t k, dN;
+    double red[HTN_MAX_SITE * HTN_MAX_SITE];
+} htn_site_op;
+
+typedef struct {
+    int32_t wl, wr;          /* level on the left / right MPO bond of this site */
+    int32_t op;              /* index into the site-operator table             */
+    int32_t pad;
+    double coef_re, coef_im;
+} htn_mpo_entry;
+
+/* one sub-block of a site tensor inside the caller's flat vector: A[(l, s) ; r] as an n_l x n_r column-major
+ * matrix at data[off] with leading dimension ld (TensorKit fusion-tree view) */
+typedef struct {
+    int32_t lN, lj, s, rN, rj;
+    int32_t ld;
+    int64_t off;
+} htn_subblock;
+
+typedef struct {
+    int32_t N, j, count;
+} htn_sector;
+
+/* truncation + solver settings of one bond update / sweep */
+typedef struct {
+    int32_t chi_full;          /* truncdim(D), src:1363-1365, in TensorKit dim units (sum (2S+1) n); <= 0: off      */
+    int32_t weighting;         /* order at the truncdim cut: 0 = sqrt(2S+1) x Schmidt value, 1 = Schmidt value       */
+    double cutoff;             /* truncbelow(eta), src:1007-1010: keep Schmidt values > eta; 0: off                  */
+    int32_t krylovdim;         /* 30 (KrylovKit / MPSKit default)                                                    */
+    int32_t maxrestart;
+    double lanczos_tol;
+    double jacobi_tol;         /* 1e-14 */
+    int32_t jacobi_max_sweeps; /* 40 */
+    int32_t svd_split_elems;   /* htn_svd_opts.split_elems; 0 = default */
+    double rank_cut;           /* 0 = off (parity-exact); see DESIGN.md section 4 */
+    int32_t profile;           /* 1: synchronise around the stages so that the t_* fields are GPU-inclusive          */
+    int32_t pad;
+} htn_sweep_opts;
+
+typedef struct {
+    int32_t bond, direction;
+    int32_t n_matvec, jacobi_sweeps;
+    int32_t chi_full, multiplets;
+    int32_t n_tiles, n_segs;
+    int64_t theta_size;
+    int64_t apply_flops, apply_bytes, svd_flops;
+    double energy, residual, trunc_weight;
+    double t_plan, t_lanczos, t_svd, t_env, t_total;   /* host wall seconds per stage */
+    double matvec_ms;                                    /* HIP-event time of the H_eff apply launches (if timed) */
+} htn_bond_stats;
+
+/* context: one device, one stream (NULL: the library creates its own), one host thread at a time.
+ * backend: HTN_BACKEND_HIP is the product.  libhubbardtn_cpu.so (built from oracle/cpu_backend, the CPU baseline of
+ * SURVEY 8d) exports the same ABI with HTN_BACKEND_CPU; neither library contains the other's backend and nothing
+ * falls back. */
+#define HTN_BACKEND_CPU 0
+#define HTN_BACKEND_HIP 1
+int htn_ctx_create(int32_t backend, int32_t device, void* stream, htn_ctx** out);
+void htn_ctx_destroy(htn_ctx* ctx);
+int htn_ctx_backend(const htn_ctx* ctx);
+/* record HIP events around every H_eff apply launch (htn_bond_stats.matvec_ms); costs two event records per matvec */
+int htn_ctx_set_timing(htn_ctx* ctx, int32_t on);
+
+/* sector-parallel effective-H apply: rank r of `world` computes output tiles r, r + world, ... of every
+ * apply and the partial results are summed by ONE all-reduce per matvec on the context's stream.
+ *  - htn_comm_unique_id + htn_ctx_set_comm: RCCL over xGMI, called from inside the library (HIP backend);
+ *    the 128-byte id is created on rank 0 and distributed by the caller (torch.distributed, MPI, a file, ...)
+ *  - htn_ctx_set_exchange: caller-supplied reduction (host callback, invoked after each matvec has been enqueued
+ *    with the device pointer of y); a non-zero return aborts the solve.  Used by the gloo/CPU rehearsal tests. */
+#define HTN_COMM_ID_BYTES 128
+int htn_comm_unique_id(void* id_host);
+int htn_ctx_set_comm(htn_ctx* ctx, int32_t rank, int32_t world, const void* id_host);
+int htn_ctx_set_exchange(htn_ctx* ctx, int32_t rank, int32_t world, htn_exchange2_fn fn, void* user);
+
+/* MPO of a chain of nsites sites.  level_ptr[nsites + 2]: levels (dN, k pairs) of bond b (between site b-1 and b,
+ * b = 0 .. nsites) are levels[2 * level_ptr[b] .. 2 * level_ptr[b + 1]); entry_ptr[nsites + 1]: entries of site i.
+ * Level 0 of an interior bond is the identity "nothing applied yet", the last level "term complete" (Jordan form,
+ * SURVEY App. A.3); the boundary bonds hold exactly one level. */
+int htn_mpo_create(htn_ctx* ctx, const htn_symmetry* sym, int32_t nsites, const htn_site_op* ops_host, int32_t n_ops,
+                   const int32_t* level_ptr_host, const int32_t* levels_host, const int32_t* entry_ptr_host,
+                   const htn_mpo_entry* entries_host, htn_mpo** out);
+void htn_mpo_destroy(htn_mpo* mpo);
+
+/* MPS + environments of a finite chain (or of an iDMRG window between two blocks).  bond_ptr[nsites + 2]: sectors of
+ * bond b are sectors[bond_ptr[b] .. bond_ptr[b + 1]).  Site tensors must be right-canonical for sites >= 1 (site 0
+ * carries the centre), "tilde" normalised.  sub_ptr[nsites + 1] indexes `subs`; data_ptr[nsites
+ * + 1] (element offsets) indexes data_host, sub-block offsets are relative to their site's start.
+ * left_env / right_env (may be NULL = open end): the boundary environments in the library's block order
+ * (htn_mps_env_size / htn_mps_get_env of the engine they come from). */
+int htn_mps_create(htn_ctx* ctx, const htn_mpo* mpo, int32_t nsites, const int32_t* bond_ptr_host,
+                   const htn_sector* sectors_host, const int32_t* sub_ptr_host, const htn_subblock* subs_host,
+                   const int64_t* data_ptr_host, const void* data_host, const void* left_env_host,
+                   const void* right_env_host, htn_mps** out);
+void htn_mps_destroy(htn_mps* mps);
+
+/* one two-site update of sites (i, i+1) (0-based): form theta, lowest eigenpair of H_eff (optimise = 1) or
+ * <theta|H|theta> only (optimise = 0: the centre is moved without optimisation), per-sector SVD + global truncation,
+ * write back (placement 0 'right': A_i = U, centre S V^H on i+1; 1 'left': centre U S on i, B_{i+1} = V^H) and
+ * move the environment.  stats may be NULL. */
+int htn_bond_update(htn_mps* mps, int32_t i, int32_t direction, int32_t placement, int32_t optimise,
+                    const htn_sweep_opts* opts, htn_bond_stats* stats_host);
+/* one sweep in MPSKit's DMRG2 order: bonds 1..L-1 rightwards, L-2..1 leftwards (2L-3 updates);
+ * stats_host: 2L-3 records or NULL; energy_host receives the last eigenvalue */
+int htn_dmrg2_sweep(htn_mps* mps, const htn_sweep_opts* opts, htn_bond_stats* stats_host, double* energy_host);
+
+/* y = H_eff(bond i, i+1) x on host vectors in the library's theta layout (size htn_mps_theta_size); tests and
+ * Hermiticity checks.  x and y are complex128 host arrays. */
+int64_t htn_mps_theta_size(htn_mps* mps, int32_t i);
+int htn_heff2_apply(htn_mps* mps, int32_t i, const void* x_host, void* y_host);
+/* theta of sites (i, i+1) as currently stored (host, theta layout) */
+int htn_mps_get_theta(htn_mps* mps, int32_t i, void* theta_host);
+
+/* queries (two-call pattern: a NULL output pointer returns the count only) */
+int32_t htn_mps_nsites(const htn_mps* mps);
+int32_t htn_mps_bond(const htn_mps* mps, int32_t b, htn_sector* sectors_host);              /* -> number of sectors  */
+int64_t htn_mps_spectrum(const htn_mps* mps, int32_t b, htn_sector* sectors_host, double* values_host);
+                                        /* Schmidt values of the last update of bond b, per sector descending;
+                                           sectors[k].count values each; returns the total number of values */
+int64_t htn_mps_site_size(const htn_mps* mps, int32_t i, int32_t* kind_host);               /* kind: 'L' or 'R'      */
+int32_t htn_mps_get_site(const htn_mps* mps, int32_t i, htn_subblock* subs_host, void* data_host);  /* -> #sub-blocks */
+int64_t htn_mps_env_size(const htn_mps* mps, int32_t side, int32_t b);                      /* side 0 = left, 1 = right */
+int htn_mps_get_env(const htn_mps* mps, int32_t side, int32_t b, void* data_host);
+/* block table of an environment: per block (bra N, bra j, level, ket N, ket j, offset lo, offset hi32 = 0, rows, cols)
+ * as 9 int32... use htn_env_block */
+typedef struct {
+    int32_t aN, aj, w, bN, bj;     /* left env: (bra, w, ket) stored [n_bra x n_ket]; right env: (ket, w, bra) [n_ket x n_bra] */
+    int32_t rows, cols;
+    int32_t pad;
+    int64_t off;
+} htn_env_block;
+int32_t htn_mps_env_blocks(const htn_mps* mps, int32_t side, int32_t b, htn_env_block* blocks_host);
+/* planner introspection (tests): the task lists of the H_eff apply on bond i as the kernels receive them.
+ * stage 0 = Z stage (may be empty), 1 = Y stage.  Returns counts through n_tiles / n_segs; tiles / segs may be NULL. */
+int htn_plan_apply_dump(htn_mps* mps, int32_t i, int32_t stage, int32_t* n_tiles, htn_tile* tiles_host, int32_t* n_segs,
+                        htn_seg* segs_host, int64_t* z_size, int64_t* flops);
+/* plan-cache statistics: hits, misses (host planner invocations) */
+int htn_mps_cache_stats(const htn_mps* mps, int64_t* hits, int64_t* misses);
 
 #ifdef __cplusplus
 }

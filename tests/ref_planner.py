@@ -1,4 +1,7 @@
-"""Host planner: turns sector tables + a reduced MPO into the task lists the HIP kernels execute.
+"""TEST STATEMENT of the contraction planner (the product's planner is C++: hubbardtn_amd/csrc/htn_plan.cpp;
+tests/test_cplan_cpu.py asserts that both emit byte-identical task lists).
+
+Host planner: turns sector tables + a reduced MPO into the task lists the HIP kernels execute.
 
 This is the MI355X-first replacement for what TensorKit does with fusion trees and tree
 transformers around every contraction: instead of permuting
@@ -22,9 +25,10 @@ from math import sqrt
 
 import numpy as np
 
-from .abi import COPY_DT, OP_C, OP_N, OP_T, SEG_COPY, SEG_DT, SEG_GEMM, SVD_DT, TILE_DT, HTN_TILE
-from .models import SITE_MULT, SITE_OPS
-from .wigner import triangle, wigner9j
+from hubbardtn_amd.abi import COPY_DT, OP_C, OP_N, OP_T, SEG_COPY, SEG_DT, SEG_GEMM, SVD_DT, TILE_DT, HTN_TILE
+from hubbardtn_amd.models import SITE_MULT, SITE_OPS
+from hubbardtn_amd.sectors import Bond, full_bonds, fuse, split
+from ref_wigner import triangle, wigner9j
 
 # buffer-table slots shared by all plans
 BUF_X, BUF_Y, BUF_L, BUF_R, BUF_Z, BUF_S1, BUF_S2, BUF_AUX = range(8)
@@ -56,77 +60,6 @@ def coef_apply(ja, jap, k, js1, js1p, kop1, km, jc, jcp, js2, js2p, kop2, kp, jb
 # ----------------------------------------------------------------------------------------------
 # sectors, bonds, layouts
 # ----------------------------------------------------------------------------------------------
-def fuse(sec, s):
-    N, j = sec
-    Ns, js = SITE_MULT[s]
-    return [(N + Ns, jj) for jj in range(abs(j - js), j + js + 1, 2)]
-
-
-def split(sec, s):
-    N, j = sec
-    Ns, js = SITE_MULT[s]
-    if N < Ns:
-        return []
-    return [(N - Ns, jj) for jj in range(abs(j - js), j + js + 1, 2)]
-
-
-class Bond:
-    """ordered sector table of one virtual bond: sector (N, twoS) -> multiplet count"""
-
-    def __init__(self, dims: dict):
-        items = sorted((k, int(v)) for k, v in dims.items() if v > 0)
-        self.secs = [k for k, _ in items]
-        self.dims = {k: v for k, v in items}
-        self._key = tuple(items)
-
-    def __contains__(self, sec):
-        return sec in self.dims
-
-    def __getitem__(self, sec):
-        return self.dims[sec]
-
-    def __iter__(self):
-        return iter(self.secs)
-
-    def __eq__(self, other):
-        return isinstance(other, Bond) and self.dims == other.dims
-
-    def key(self):
-        return self._key
-
-    @property
-    def dim_full(self):
-        """TensorKit `dim` (SU(2)-expanded), the unit `dim_state` prints (src:1399-1405)"""
-        return sum((j + 1) * n for (N, j), n in self.dims.items())
-
-    @property
-    def multiplets(self):
-        return sum(self.dims.values())
-
-
-def full_bonds(nsites, target):
-    """exact (untruncated) bond tables of an open chain with total sector `target`"""
-    left = [{(0, 0): 1}]
-    for _ in range(nsites):
-        nxt = {}
-        for sec, n in left[-1].items():
-            for s in range(3):
-                for c in fuse(sec, s):
-                    nxt[c] = nxt.get(c, 0) + n
-        left.append(nxt)
-    right = [{target: 1}]
-    for _ in range(nsites):
-        prv = {}
-        for sec, n in right[-1].items():
-            for s in range(3):
-                for c in split(sec, s):
-                    prv[c] = prv.get(c, 0) + n
-        right.append(prv)
-    right = right[::-1]
-    return [Bond({sec: min(left[i][sec], right[i][sec]) for sec in left[i] if sec in right[i]})
-            for i in range(nsites + 1)]
-
-
 @dataclass
 class SiteLayout:
     """layout of a one-site tensor between bond_l and bond_r; kind 'L' groups by the right

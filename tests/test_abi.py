@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_functions():
     src = open(os.path.join(ROOT, "include", "hubbardtn_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(htn_[a-z0-9_]+)\s*\(", src)) - {"htn_exchange_fn"})
+    return sorted(set(re.findall(r"\b(htn_[a-z0-9_]+)\s*\(", src)) - {"htn_exchange2_fn"})
 
 
 def test_library_exports_every_declared_symbol():
@@ -22,9 +22,27 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 12
     for n in names:
         assert hasattr(lib, n), n
-    assert sorted(abi.EXPORTS) == names
-    assert lib.htn_abi_version() == 1
+    assert sorted(abi.EXPORTS + abi.ENGINE_EXPORTS) == names
+    assert lib.htn_abi_version() == 2
     assert lib.htn_last_error() == b""
+
+
+def test_cpu_baseline_library_exports_the_engine_level_abi():
+    """oracle/cpu_backend builds the same planner / sweep-driver sources against host kernels: every bond-update / sweep
+    entry point of the header exists there too, and neither library contains the other's backend"""
+    import ctypes as C
+    from oracle.cpu_backend import build as cpu_build
+    lib = C.CDLL(cpu_build.build_library(verbose=False))
+    abi.declare_engine(lib)
+    for n in abi.ENGINE_EXPORTS:
+        assert hasattr(lib, n), n
+    assert lib.htn_abi_version() == 2
+    for n in ("htn_grouped_gemm_z", "htn_jacobi_svd_z", "htn_lanczos_z"):       # kernel-level entry points are HIP only
+        assert not hasattr(lib, n)
+    hip = abi.load_library()
+    ctx = C.c_void_p()
+    assert hip.htn_ctx_create(abi.BACKEND_CPU, 0, None, C.byref(ctx)) != 0      # the product has no CPU backend
+    assert b"no CPU" in hip.htn_last_error()
 
 
 def test_struct_layouts_match_header():

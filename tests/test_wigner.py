@@ -3,8 +3,8 @@ import itertools
 
 import numpy as np
 
-from hubbardtn_amd import planner as pl
-from hubbardtn_amd.wigner import triangle, wigner6j, wigner9j
+import ref_planner as pl
+from ref_wigner import triangle, wigner6j, wigner9j
 from oracle import su2
 
 
