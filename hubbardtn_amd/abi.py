@@ -21,7 +21,10 @@ SEG_GEMM, SEG_COPY = 0, 1
 # numpy mirrors of the C structs (sizes asserted against the header's comments)
 TILE_DT = np.dtype([("c_off", "<i8"), ("buf_c", "<i4"), ("ldc", "<i4"), ("m", "<i4"), ("n", "<i4"),
                     ("row0", "<i4"), ("col0", "<i4"), ("seg_begin", "<i4"), ("seg_count", "<i4"),
-                    ("pad0", "<i4"), ("pad1", "<i4")], align=False)
+                    ("pad0", "<i4"), ("pad1", "<i4"), ("part", "<i4"), ("nparts", "<i4"), ("ws_slot", "<i4"),
+                    ("ticket", "<i4")], align=False)
+BUF_WS = 7                          # buffer-table slot of the split-K workspace
+WS_TICKET_ELEMS = 4096              # complex128 elements reserved for the tickets
 SEG_DT = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("buf_a", "<i4"), ("buf_b", "<i4"),
                    ("lda", "<i4"), ("ldb", "<i4"), ("k", "<i4"), ("op_a", "<i4"), ("op_b", "<i4"),
                    ("type", "<i4"), ("alpha_re", "<f8"), ("alpha_im", "<f8")], align=False)
@@ -32,7 +35,7 @@ SVD_QRCP = 2
 COPY_DT = np.dtype([("dst_off", "<i8"), ("src_off", "<i8"), ("idx_off", "<i8"), ("scl_off", "<i8"),
                     ("rows", "<i4"), ("cols", "<i4"), ("ldd", "<i4"), ("lds", "<i4"), ("op", "<i4"),
                     ("gather_dim", "<i4"), ("scale_dim", "<i4"), ("inv_norm", "<i4")], align=False)
-assert TILE_DT.itemsize == 48 and SEG_DT.itemsize == 64 and SVD_DT.itemsize == 40 and COPY_DT.itemsize == 64
+assert TILE_DT.itemsize == 64 and SEG_DT.itemsize == 64 and SVD_DT.itemsize == 40 and COPY_DT.itemsize == 64
 
 # ---- bond-update / sweep level (ABI 2) ----
 SYM_SU2_U1, SYM_U1_U1, SYM_SU2 = 0, 1, 2
@@ -83,8 +86,8 @@ ENGINE_EXPORTS = ["htn_ctx_create", "htn_ctx_destroy", "htn_ctx_backend", "htn_c
                   "htn_ctx_set_comm", "htn_ctx_set_exchange", "htn_mpo_create", "htn_mpo_destroy", "htn_mps_create",
                   "htn_mps_destroy", "htn_bond_update", "htn_dmrg2_sweep", "htn_mps_theta_size", "htn_heff2_apply",
                   "htn_mps_get_theta", "htn_mps_nsites", "htn_mps_bond", "htn_mps_spectrum", "htn_mps_site_size",
-                  "htn_mps_get_site", "htn_mps_env_size", "htn_mps_get_env", "htn_mps_env_blocks",
-                  "htn_plan_apply_dump", "htn_mps_cache_stats"]
+                  "htn_mps_get_site", "htn_mps_env_size", "htn_mps_get_env", "htn_mps_env_blocks", "htn_mps_env_bond",
+                  "htn_plan_apply_dump", "htn_mps_cache_stats", "htn_balance_tiles"]
 
 
 class GemmLaunch(C.Structure):
@@ -180,9 +183,11 @@ def declare_engine(lib):
     lib.htn_mps_env_size.restype = i64
     lib.htn_mps_get_env.argtypes = [vp, i32, i32, vp]
     lib.htn_mps_env_blocks.argtypes = [vp, i32, i32, vp]
+    lib.htn_mps_env_bond.argtypes = [vp, i32, i32, vp]
     lib.htn_plan_apply_dump.argtypes = [vp, i32, i32, C.POINTER(i32), vp, C.POINTER(i32), vp, C.POINTER(i64),
                                         C.POINTER(i64)]
     lib.htn_mps_cache_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    lib.htn_balance_tiles.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
     for name in ENGINE_EXPORTS:
         getattr(lib, name)
 

@@ -62,15 +62,18 @@ struct HipBackend : htn::Backend {
     void* lan_scratch = nullptr;
     int64_t lan_scratch_elems = 0;
     void* comm = nullptr;
+    char* stage = nullptr;                        // pinned host staging ring of upload()
+    size_t stage_cap = (size_t)32 << 20, stage_pos = 0;
 
     ~HipBackend() override {
-        hipSetDevice(device);
-        if (st) hipStreamSynchronize(st);
+        (void)hipSetDevice(device);
+        if (st) (void)hipStreamSynchronize(st);
         if (comm && rccl().ok) rccl().CommDestroy(comm);
-        for (auto& kv : free_list) hipFree(kv.second);
-        for (auto& kv : live) hipFree(kv.first);
-        if (lan_scratch) hipFree(lan_scratch);
-        if (own_stream && st) hipStreamDestroy(st);
+        for (auto& kv : free_list) (void)hipFree(kv.second);
+        for (auto& kv : live) (void)hipFree(kv.first);
+        if (lan_scratch) (void)hipFree(lan_scratch);
+        if (stage) (void)hipHostFree(stage);
+        if (own_stream && st) (void)hipStreamDestroy(st);
     }
     int kind() const override { return HTN_BACKEND_HIP; }
 
@@ -90,8 +93,8 @@ struct HipBackend : htn::Backend {
         if (hipMalloc(&p, want) != hipSuccess) {
             // give the pool back to the driver and retry once with the exact size
             (void)hipGetLastError();
-            hipStreamSynchronize(st);
-            for (auto& kv : free_list) hipFree(kv.second);
+            (void)hipStreamSynchronize(st);
+            for (auto& kv : free_list) (void)hipFree(kv.second);
             free_list.clear();
             pooled = 0;
             if (hipMalloc(&p, bytes) != hipSuccess) {
@@ -110,22 +113,41 @@ struct HipBackend : htn::Backend {
         const size_t sz = it->second;
         live.erase(it);
         if (pooled + sz > ((size_t)64 << 30)) {      // keep at most 64 GiB of the 288 parked in the pool
-            hipStreamSynchronize(st);
-            hipFree(p);
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(p);
             return;
         }
         free_list.insert({sz, p});
         pooled += sz;
     }
+    // Host -> device through a pinned staging ring owned by the backend: the caller's (pageable, often short-lived)
+    // source is copied out before this returns, the DMA itself is asynchronous on the stream.  (hipMemcpyAsync from
+    // pageable memory pins the user's pages and returns before the transfer for larger sizes: a plan's std::vector
+    // freed right after the call would be read after free.)
     int upload(void* dst, const void* src, size_t bytes) override {
         if (!bytes) return 0;
-        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));      // pageable source: staged before return
+        if (bytes > stage_cap / 2) {
+            HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            stage_pos = 0;
+            return 0;
+        }
+        if (!stage) HIP_TRY(hipHostMalloc((void**)&stage, stage_cap));
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (stage_pos + need > stage_cap) {
+            HIP_TRY(hipStreamSynchronize(st));
+            stage_pos = 0;
+        }
+        memcpy(stage + stage_pos, src, bytes);
+        HIP_TRY(hipMemcpyAsync(dst, stage + stage_pos, bytes, hipMemcpyHostToDevice, st));
+        stage_pos += need;
         return 0;
     }
     int download(void* dst, const void* src, size_t bytes) override {
         if (!bytes) return 0;
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        stage_pos = 0;                        // everything enqueued before has completed: the ring is free again
         return 0;
     }
     int zero(void* p, size_t bytes) override {
@@ -135,6 +157,7 @@ struct HipBackend : htn::Backend {
     }
     int sync() override {
         HIP_TRY(hipStreamSynchronize(st));
+        stage_pos = 0;
         return 0;
     }
     int grouped_gemm(const void* const* bufs, const htn_tile* tiles, int32_t n_tiles, const htn_seg* segs) override {

@@ -216,6 +216,13 @@ struct Tasks {
     int64_t flops = 0;           // algorithmic complex128 flops (8 per MAC) of the GEMM segments
 };
 
+// Load balance of one grouped-GEMM launch (HIP backend): the launch is bound by its longest tile's dependent K loop,
+// so tiles with more than ~(total slabs / CUs) K slabs are cut into parts (htn_tile.part / nparts) that run on
+// different workgroups and meet through the split-K workspace; the records are then ordered longest first and dealt
+// so that tiles sharing operand panels (same output block and row strip) land on the same XCD's L2 under the
+// round-robin workgroup placement.  Returns the number of workspace slabs the list uses (0: nothing was split).
+int balance_tiles(Tasks& t, int n_cus);
+
 struct ApplyPlan {
     Tasks tz, ty;
     bool has_z = false;

@@ -10,6 +10,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
 
@@ -20,7 +21,10 @@ Backend* make_backend(int backend, int device, void* stream);       // one per l
 }
 using namespace htn;
 
+// Handles are reference counted: an htn_mps keeps its context and its MPO alive, so destroying the handles in any order
+// (garbage-collected host languages do exactly that) is safe; the last release frees the object.
 struct htn_ctx {
+    std::atomic<int> refs{1};
     std::unique_ptr<Backend> be;
     int rank = 0, world = 1;
     bool shard = false;              // zero y + reduce after every matvec (world > 1, or forced for tests)
@@ -28,9 +32,20 @@ struct htn_ctx {
     void* exch_user = nullptr;
 };
 struct htn_mpo {
+    std::atomic<int> refs{1};
     htn_ctx* ctx;
     Mpo mpo;
 };
+static void ctx_release(htn_ctx* c) {
+    if (c && --c->refs == 0) delete c;
+}
+static void mpo_release(htn_mpo* m) {
+    if (m && --m->refs == 0) {
+        htn_ctx* c = m->ctx;
+        delete m;
+        ctx_release(c);
+    }
+}
 
 namespace {
 
@@ -59,6 +74,7 @@ struct DevTasks {
     const htn_tile* tiles = nullptr;
     const htn_seg* segs = nullptr;
     int32_t ntiles = 0, nsegs = 0;
+    int32_t ws_slots = 0;          // split-K workspace slabs the list needs (balance_tiles)
     int64_t flops = 0;
 };
 
@@ -95,6 +111,7 @@ struct Spectrum {
 
 struct htn_mps {
     htn_ctx* ctx;
+    htn_mpo* mpo_handle = nullptr;
     Backend* be;
     const Mpo* mpo;
     int L;
@@ -138,7 +155,28 @@ struct htn_mps {
         if (v.base && zero) be->zero(v.base->p, sizeof(cplx) * (size_t)std::max<int64_t>(n, 1));
         return v;
     }
-    int upload_tasks(const Tasks& t, DevTasks& d) {
+    DView ws;                      // split-K workspace of the grouped GEMM: [tickets | slabs], grown on demand
+    int64_t ws_slots = -1;
+    int ensure_ws(int slots) {
+        if (slots <= ws_slots) return 0;
+        const int64_t want = std::max<int64_t>(2 * (int64_t)slots, 256);
+        ws = zalloc(HTN_WS_ELEMS(want), false);
+        if (!ws.base) return set_error("device allocation of the split-K workspace failed");
+        if (be->zero(ws.ptr(), sizeof(cplx) * HTN_WS_TICKET_ELEMS)) return 1;      // tickets start at zero; the kernel resets them
+        ws_slots = want;
+        return 0;
+    }
+    int upload_tasks(const Tasks& t_in, DevTasks& d) {
+        Tasks balanced;
+        const Tasks* tp = &t_in;
+        d.ws_slots = 0;
+        if (be->kind() == HTN_BACKEND_HIP && t_in.ntiles > 0) {        // (the CPU baseline runs tiles as they are)
+            balanced = t_in;
+            balanced.tiles.resize((size_t)t_in.ntiles);
+            d.ws_slots = balance_tiles(balanced, 256);
+            tp = &balanced;
+        }
+        const Tasks& t = *tp;
         const size_t tb = (sizeof(htn_tile) * t.tiles.size() + 63) / 64 * 64, sb = sizeof(htn_seg) * t.segs.size();
         d.mem = dalloc(tb + sb);
         if (!d.mem) return set_error("device allocation of a task list failed");
@@ -151,6 +189,7 @@ struct htn_mps {
         d.flops = t.flops;
         return 0;
     }
+    // (htn_plan_apply_dump shows the lists BEFORE balancing: those are what the Python statement of the planner emits)
     SiteLayoutP site_layout(char kind, BondP bl, BondP br) {
         return cached<const SiteLayout>(std::string("slay") + kind + bl->key + "|" + br->key,
                                         [&] { return build_site_layout(mpo->sym, kind, bl, br); });
@@ -161,8 +200,10 @@ struct htn_mps {
     }
     int gemm(const DevTasks& d, std::initializer_list<std::pair<int, const void*>> bufs) {
         if (d.ntiles == 0) return 0;
+        if (ensure_ws(d.ws_slots)) return 1;
         const void* table[HTN_MAX_BUFS] = {nullptr};
         for (auto& kv : bufs) table[kv.first] = kv.second;
+        table[HTN_BUF_WS] = ws.ptr();
         return be->grouped_gemm(table, d.tiles, d.ntiles, d.segs);
     }
 
@@ -287,8 +328,10 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
     auto ap = make_apply(i, tl);
     if (!ap) return 1;
     DView z = zalloc(ap->zsize, false);
+    if (ensure_ws(std::max(ap->dy.ws_slots, ap->has_z ? ap->dz.ws_slots : 0))) return 1;
     htn_gemm_launch stages[2];
     memset(stages, 0, sizeof(stages));
+    stages[0].bufs[HTN_BUF_WS] = stages[1].bufs[HTN_BUF_WS] = ws.ptr();
     int ns = 0;
     if (ap->has_z) {
         stages[ns].bufs[BUF_L] = Lbuf[i].ptr();
@@ -327,9 +370,11 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
     const SvdPlan& sp = sc->sp;
     const int nb = (int)sp.mids.size();
     DView G = zalloc(sp.g_size, false), Vj = zalloc(sp.v_size, false);
-    DBufP S = dalloc(sizeof(double) * (size_t)std::max<int64_t>(sp.s_size, 1));
-    DBufP info = dalloc(sizeof(int32_t) * (size_t)std::max(nb, 1));
-    if (!G.base || !Vj.base || !S || !info) return set_error("device allocation failed (SVD workspace)");
+    // singular values and per-block sweep counts share one buffer: ONE device-to-host copy (one stream sync) per bond
+    const size_t s_elems = (size_t)std::max<int64_t>(sp.s_size, 1), i_elems = (size_t)std::max(nb, 1);
+    DBufP S = dalloc(sizeof(double) * s_elems + sizeof(int32_t) * i_elems);
+    if (!G.base || !Vj.base || !S) return set_error("device allocation failed (SVD workspace)");
+    int32_t* info_dev = (int32_t*)((double*)S->p + s_elems);
     if (be->batched_copy(G.ptr(), x, nullptr, nullptr, (const htn_copy_item*)sc->stage->p, nb, 1.0)) return 1;
     // Singular directions far below what the truncation keeps need not be resolved (optional, OFF by default).
     // truncbelow(eta): everything below eta goes anyway.  truncdim(D): if the previous update of this bond (same D) was
@@ -347,12 +392,11 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
     }
     if (be->jacobi_svd(G.ptr(), Vj.ptr(), (double*)S->p, (const htn_svd_block*)sc->desc->p, sp.desc.data(), nb, sp.max_m,
                        o.jacobi_max_sweeps > 0 ? o.jacobi_max_sweeps : 40, o.jacobi_tol > 0.0 ? o.jacobi_tol : 1e-14,
-                       (int32_t*)info->p, &so))
+                       info_dev, &so))
         return 1;
-    std::vector<double> s_host((size_t)std::max<int64_t>(sp.s_size, 1));
-    std::vector<int32_t> info_h((size_t)std::max(nb, 1));
-    if (be->download(s_host.data(), S->p, sizeof(double) * s_host.size())) return 1;
-    if (be->download(info_h.data(), info->p, sizeof(int32_t) * info_h.size())) return 1;
+    std::vector<double> s_host(s_elems + (i_elems + 1) / 2);
+    if (be->download(s_host.data(), S->p, sizeof(double) * s_elems + sizeof(int32_t) * i_elems)) return 1;
+    const int32_t* info_h = (const int32_t*)(s_host.data() + s_elems);
     int jac_sweeps = 0;
     for (int b = 0; b < nb; ++b) {
         if (info_h[b] < 0) return set_error("Jacobi SVD did not converge (bond %d, block %d, %d sweeps)", i + 1, b, -info_h[b]);
@@ -487,7 +531,7 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
         st->t_svd = t_svd;
         st->t_env = t_env;
         st->t_total = now() - t0;
-        st->matvec_ms = mv_ms;
+        st->matvec_ms = mv_ms > 0.0 ? mv_ms : 0.0;      // (0: none of this solve's launches fell on the 1-in-8 timing sample)
     }
     return 0;
 }
@@ -519,7 +563,7 @@ int htn_ctx_create(int32_t backend, int32_t device, void* stream, htn_ctx** out)
     *out = c;
     return 0;
 }
-void htn_ctx_destroy(htn_ctx* ctx) { delete ctx; }
+void htn_ctx_destroy(htn_ctx* ctx) { ctx_release(ctx); }
 int htn_ctx_backend(const htn_ctx* ctx) { return ctx->be->kind(); }
 int htn_ctx_set_timing(htn_ctx* ctx, int32_t on) {
     ctx->be->timing = on != 0;
@@ -594,18 +638,29 @@ int htn_mpo_create(htn_ctx* ctx, const htn_symmetry* sym, int32_t nsites, const 
         // a window inside a larger system (iDMRG) has full-width boundary bonds: allowed, the boundary environments
         // then must be supplied to htn_mps_create
     }
+    ++ctx->refs;
     *out = m.release();
     return 0;
 }
-void htn_mpo_destroy(htn_mpo* mpo) { delete mpo; }
+void htn_mpo_destroy(htn_mpo* mpo) { mpo_release(mpo); }
 
 int htn_mps_create(htn_ctx* ctx, const htn_mpo* mpo, int32_t nsites, const int32_t* bond_ptr, const htn_sector* sectors,
                    const int32_t* sub_ptr, const htn_subblock* subs, const int64_t* data_ptr, const void* data_host,
                    const void* left_env_host, const void* right_env_host, htn_mps** out) {
     if (!ctx || !mpo || !out) return set_error("htn_mps_create: NULL argument");
     if (nsites != (int)mpo->mpo.sites.size()) return set_error("htn_mps_create: %d sites but the MPO has %d", nsites, (int)mpo->mpo.sites.size());
-    auto e = std::make_unique<htn_mps>();
+    // (errors below return through the guard: it drops the references the half-built object took)
+    struct Guard {
+        htn_mps* p;
+        ~Guard() {
+            if (p) htn_mps_destroy(p);
+        }
+    } guard{new htn_mps()};
+    htn_mps* e = guard.p;
     e->ctx = ctx;
+    ++ctx->refs;
+    e->mpo_handle = const_cast<htn_mpo*>(mpo);
+    ++e->mpo_handle->refs;
     e->be = ctx->be.get();
     e->mpo = &mpo->mpo;
     e->L = nsites;
@@ -658,10 +713,18 @@ int htn_mps_create(htn_ctx* ctx, const htn_mpo* mpo, int32_t nsites, const int32
     for (int i = nsites - 1; i >= 1; --i)
         if (e->right_env(i)) return 1;
     if (e->be->sync()) return 1;
-    *out = e.release();
+    guard.p = nullptr;
+    *out = e;
     return 0;
 }
-void htn_mps_destroy(htn_mps* mps) { delete mps; }
+void htn_mps_destroy(htn_mps* mps) {
+    if (!mps) return;
+    htn_ctx* c = mps->ctx;
+    htn_mpo* m = mps->mpo_handle;
+    delete mps;              // device buffers go back to the backend's pool first ...
+    mpo_release(m);          // ... then the references that kept the backend alive
+    ctx_release(c);
+}
 
 static htn_sweep_opts norm_opts(const htn_sweep_opts* o) {
     htn_sweep_opts d;
@@ -765,6 +828,15 @@ int htn_mps_get_env(const htn_mps* mps, int32_t side, int32_t b, void* data_host
     if (l->size == 0) return 0;
     return mps->be->download(data_host, (side == 0 ? mps->Lbuf[b] : mps->Rbuf[b]).ptr(), sizeof(cplx) * l->size);
 }
+int32_t htn_mps_env_bond(const htn_mps* mps, int32_t side, int32_t b, htn_sector* out) {
+    if (b < 0 || b > mps->L) return -1;
+    const EnvLayoutP& l = side == 0 ? mps->Llay[b] : mps->Rlay[b];
+    if (!l) return -1;
+    const Bond& B = *l->bond;
+    if (out)
+        for (size_t k = 0; k < B.secs.size(); ++k) out[k] = {B.secs[k].N, B.secs[k].j, B.dims[k]};
+    return (int32_t)B.secs.size();
+}
 int32_t htn_mps_env_blocks(const htn_mps* mps, int32_t side, int32_t b, htn_env_block* out) {
     if (b < 0 || b > mps->L) return -1;
     const EnvLayoutP& l = side == 0 ? mps->Llay[b] : mps->Rlay[b];
@@ -791,6 +863,21 @@ int htn_plan_apply_dump(htn_mps* mps, int32_t i, int32_t stage, int32_t* n_tiles
     if (z_size) *z_size = p.zsize;
     if (flops) *flops = have ? t.flops : 0;
     return 0;
+}
+int32_t htn_balance_tiles(const htn_tile* tiles, int32_t n_tiles, int32_t n_cus, htn_tile* out, int32_t out_cap, int32_t* n_out) {
+    Tasks t;
+    t.tiles.assign(tiles, tiles + std::max(n_tiles, 0));
+    t.ntiles = n_tiles;
+    const int ws = balance_tiles(t, n_cus > 0 ? n_cus : 256);
+    if (n_out) *n_out = t.ntiles;
+    if (out) {
+        if (t.ntiles > out_cap) {
+            set_error("htn_balance_tiles: %d records do not fit the output array (%d)", t.ntiles, out_cap);
+            return -1;
+        }
+        memcpy(out, t.tiles.data(), sizeof(htn_tile) * (size_t)t.ntiles);
+    }
+    return ws;
 }
 int htn_mps_cache_stats(const htn_mps* mps, int64_t* hits, int64_t* misses) {
     if (hits) *hits = mps->hits;

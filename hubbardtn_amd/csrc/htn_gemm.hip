@@ -24,7 +24,7 @@ struct BufTable {
 };
 
 #define KB 16         // K slab depth
-#define NQ 4          // wave-quads per workgroup (split-K ways)
+#define NQ HTN_GEMM_QUADS   // wave-quads per workgroup (intra-workgroup split-K ways)
 #define LDS_LD 48     // padded leading dimension (doubles) of a 32-wide slab row: 48 = 16 mod 32 keeps
                       // the two k-rows read by one 32-lane group on disjoint banks (ds_read_b64)
 // Row kk is additionally rotated by kk inside its 32 doubles: a k-contiguous staging pass (16 lanes
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, cons
         }
     }
     __syncthreads();
-    if (q == 0 && orow < T.m) {
+    if (q == 0) {
 #pragma unroll
         for (int p = 0; p < NQ - 1; ++p) {
             const double* src = red + (p * 256 + tq) * 8;
@@ -314,6 +314,54 @@ __global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, cons
                 acc_im[r] += src[4 + r];
             }
         }
+    }
+    // ---- split-K ACROSS workgroups (nparts > 1): the tile's segment list was cut into nparts consecutive ranges, one
+    // workgroup each (the planner does this to the longest tiles: one apply is bound by its longest tile's dependent
+    // K loop, not by flops).  Every part publishes its 32 x 32 partial sum as a 16 KiB slab in the workspace
+    // (bufs.p[HTN_BUF_WS]); the part whose ticket draw is nparts - 1 adds the slabs IN PART ORDER (bit-reproducible
+    // whatever the arrival order) and writes the tile.  In-launch hand-off across CUs / XCDs: plain slab stores,
+    // vmcnt drain, workgroup barrier, ONE agent-scope release + relaxed agent ticket add; the reducer: ONE agent-scope
+    // acquire, then plain loads (cdna_hip_programming.md, "in-launch split-K reduction").  The ticket is reset by the
+    // reducer: it is zero before every launch (zero-initialised once by the owner of the workspace). ----
+    if (T.nparts > 1) {
+        double2* __restrict__ ws = bufs.p[HTN_BUF_WS];
+        int* __restrict__ tickets = (int*)ws;
+        double2* __restrict__ slab = ws + HTN_WS_TICKET_ELEMS + (int64_t)(T.ws_slot + T.part) * (HTN_TILE * HTN_TILE);
+        if (q == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[tq * 4 + r] = make_double2(acc_re[r], acc_im[r]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = (int*)lds_all;               // (the LDS planes are dead now; ONE __shared__ object in this kernel)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            flag[0] = __hip_atomic_fetch_add(&tickets[T.ticket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (flag[0] != T.nparts - 1) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&tickets[T.ticket], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (q == 0) {
+            const double2* __restrict__ s0 = ws + HTN_WS_TICKET_ELEMS + (int64_t)T.ws_slot * (HTN_TILE * HTN_TILE) + tq * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_re[r] = acc_im[r] = 0.0;
+            for (int p = 0; p < T.nparts; ++p) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 v = s0[(int64_t)p * (HTN_TILE * HTN_TILE) + r];
+                    acc_re[r] += v.x;
+                    acc_im[r] += v.y;
+                }
+            }
+        }
+    }
+    if (q == 0 && orow < T.m) {
         double2* __restrict__ Cp = bufs.p[T.buf_c] + T.c_off;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

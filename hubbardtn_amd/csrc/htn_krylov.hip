@@ -238,7 +238,10 @@ __global__ __launch_bounds__(DOT_THREADS) void k_scale_by_norm(double2* __restri
         t = wave_sum(t);
         if (tid == 0) {
             s_inv = t > 0.0 ? 1.0 / sqrt(t) : 0.0;
-            if (blockIdx.x == 0 && nrm2_out) nrm2_out[0] = t;
+            if (blockIdx.x == 0 && nrm2_out) {
+                nrm2_out[0] = t;                 // host-pinned slot: the Lanczos driver polls it (no event marker per step)
+                __threadfence_system();
+            }
         }
     }
     __syncthreads();
@@ -443,6 +446,8 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
     c2 = d_c + 64;
     nrm2 = (double*)(d_c + 128);
 
+    bool timed_step[64] = {false};
+    static thread_local unsigned step_serial = 0;
     auto matvec = [&](double2* x, double2* y) -> int {
         if (zero_y) HIP_TRY(hipMemsetAsync(y, 0, sizeof(double2) * n, st));
         for (int s = 0; s < n_stages; ++s) {
@@ -459,17 +464,37 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
     auto enqueue_step = [&](int j) -> int {
         double2* vj = V + (int64_t)j * n;
         double2* w = V + (int64_t)(j + 1) * n;
-        if (matvec_ms_host) HIP_TRY(hipEventRecord(ev_mv0[j], st));
+        // HIP events around a SAMPLE of the matvec launches (every 8th): an event is a marker packet that costs ~5 us
+        // of pipeline bubble on this part, three of them per step were 15 us of a ~105 us Lanczos step
+        const bool timed = matvec_ms_host && (step_serial % 8) == 0;
+        timed_step[j] = timed;
+        ++step_serial;
+        h_n[j] = -1.0;                               // sentinel: the step's last kernel overwrites it with |w|^2 >= 0
+        if (timed) HIP_TRY(hipEventRecord(ev_mv0[j], st));
         if (matvec(vj, w)) return 1;
-        if (matvec_ms_host) HIP_TRY(hipEventRecord(ev_mv1[j], st));
+        if (timed) HIP_TRY(hipEventRecord(ev_mv1[j], st));
         // two-pass classical Gram-Schmidt in three passes over the basis: dots | update + dots (fused) | update + norm
         launch_dots_partial(V, n, j + 1, w, n, partial, st);
         launch_axpy_dots(w, V, n, j + 1, partial, c1 + j, j, -1.0, n, partial2, st);
         hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial2, c2 + j, j,
                            -1.0, n, norm_partial);
         hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, w, w, norm_partial, n, nrm2 + j);
-        HIP_TRY(hipEventRecord(ev_done[j], st));
         return 0;
+    };
+    // wait for step j's scalars: spin on the pinned slot the step's last kernel writes (alpha was written by kernels
+    // that completed before it started: same stream).  A stream that has gone idle without the slot changing means
+    // the step never ran (a fault): report instead of spinning forever.
+    auto wait_step = [&](int j) -> int {
+        volatile double* slot = h_n + j;
+        for (unsigned spins = 1;; ++spins) {
+            if (*slot >= 0.0) return 0;
+            __builtin_ia32_pause();
+            if ((spins & 0xffff) == 0) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) return *slot >= 0.0 ? 0 : fail_msg("htn_lanczos_z: the stream drained without producing the step's norm");
+                if (q != hipErrorNotReady) return fail("hipStreamQuery", q);
+            }
+        }
     };
 
     // normalise the start vector
@@ -477,7 +502,7 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
     hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, V, V, norm_partial, n,
                        (double*)nullptr);
     double mv_ms = 0.0;
-    int nmv = 0;
+    int nmv = 0, n_timed = 0;
     double theta = 0.0, res = 0.0, beta = 0.0, amax = 0.0;
     std::vector<double> y;
     for (int restart = 0; restart <= max_restart; ++restart) {
@@ -492,11 +517,13 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
                 if (enqueue_step(j + 1)) return 1;
                 ++nmv;
             }
-            HIP_TRY(hipEventSynchronize(ev_done[j]));
-            if (matvec_ms_host) {
+            if (wait_step(j)) return 1;
+            if (timed_step[j]) {
                 float ms = 0.f;
+                HIP_TRY(hipEventSynchronize(ev_mv1[j]));
                 HIP_TRY(hipEventElapsedTime(&ms, ev_mv0[j], ev_mv1[j]));
                 mv_ms += ms;
+                ++n_timed;
             }
             const double alpha = h_c1[j].x + h_c2[j].x;
             beta = sqrt(h_n[j] > 0.0 ? h_n[j] : 0.0);
@@ -526,6 +553,7 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
     *eig_host = theta;
     *n_matvec_host = nmv;
     *residual_host = res;
-    if (matvec_ms_host) *matvec_ms_host = mv_ms;
+    // sampled launches scaled to all launches of this solve (the next solves continue the 1-in-8 sampling phase)
+    if (matvec_ms_host) *matvec_ms_host = n_timed ? mv_ms * nmv / n_timed : -1.0;
     return 0;
 }

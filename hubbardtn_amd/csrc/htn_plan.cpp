@@ -9,6 +9,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <map>
@@ -494,6 +495,93 @@ public:
 inline Key tkey(Sec a, int s1, Sec c, int s2, Sec b) { return mk(a.N, a.j, s1, c.N, c.j, s2, b.N, b.j); }
 
 }  // namespace
+
+// ---- load balance of a launch: split-K across workgroups + XCD-aware order ---------------------------------------------
+int balance_tiles(Tasks& t, int n_cus) {
+    const int nt = t.ntiles;
+    if (nt <= 0) return 0;
+    auto slabs = [](const htn_tile& T) { return std::max(0, T.seg_count - T.pad[0]); };
+    int64_t total = 0;
+    for (int i = 0; i < nt; ++i) total += slabs(t.tiles[i]);
+    // a workgroup's NQ wave-quads take NQ slabs per round: parts are sized in rounds.  cap = the balanced share of one
+    // workgroup slot (2 co-resident workgroups per CU at NQ = 2)
+    const int NQ = HTN_GEMM_QUADS;
+    const int64_t slots = (int64_t)n_cus * (4 / NQ);
+    int cap_rounds = (int)((total + NQ * slots - 1) / (NQ * slots));
+    cap_rounds = std::max(cap_rounds, 12 / NQ);        // below ~12 slabs the hand-off costs more than it saves
+    // tuning knobs for measurements (tools/apply_bench.py): rounds per part, XCD dealing on / off
+    static const int env_cap = getenv("HTN_GEMM_CAP_ROUNDS") ? atoi(getenv("HTN_GEMM_CAP_ROUNDS")) : 0;
+    static const int env_xcd = getenv("HTN_GEMM_XCD") ? atoi(getenv("HTN_GEMM_XCD")) : 1;
+    if (env_cap > 0) cap_rounds = env_cap;
+    std::vector<htn_tile> out;
+    out.reserve((size_t)nt + 64);
+    int ws = 0, tickets = 0;
+    for (int i = 0; i < nt; ++i) {
+        htn_tile T = t.tiles[i];
+        T.part = 0, T.nparts = 1, T.ws_slot = 0, T.ticket = 0;
+        const int S = slabs(T), rounds = (S + NQ - 1) / NQ;
+        int np = rounds > cap_rounds + 1 ? (rounds + cap_rounds - 1) / cap_rounds : 1;
+        if (np <= 1 || T.pad[1] == 0 || tickets >= HTN_WS_TICKET_ELEMS * 4 - 1) {
+            out.push_back(T);
+            continue;
+        }
+        const int base = rounds / np, extra = rounds % np;       // rounds per part: the first `extra` parts take one more
+        int pos = 0;
+        for (int p = 0; p < np; ++p) {
+            const int r = base + (p < extra ? 1 : 0);
+            const int cnt = std::min(NQ * r, S - pos);
+            htn_tile P = T;
+            P.seg_begin = T.seg_begin + pos;
+            P.seg_count = cnt + (p == np - 1 ? T.pad[0] : 0);     // COPY segments ride with the last part
+            P.pad[0] = p == np - 1 ? T.pad[0] : 0;
+            P.part = p, P.nparts = np, P.ws_slot = ws, P.ticket = tickets;
+            out.push_back(P);
+            pos += cnt;
+        }
+        ws += np;
+        ++tickets;
+    }
+    // longest first (LPT), then dealt over 8 XCD queues: a tile goes where its (output block, row strip) already lives,
+    // a new strip to the least loaded queue; position p of the final list runs on XCD p % 8 under round-robin placement
+    std::vector<int> order(out.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    auto cost = [&](const htn_tile& T) { return (int64_t)slabs(T) + 5; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(out[a]) > cost(out[b]); });
+    const int NX = env_xcd ? 8 : 1;
+    std::vector<std::vector<int>> q(NX);
+    int64_t load[8] = {0};
+    std::unordered_map<Key, int, KeyHash> home;
+    for (int i : order) {
+        const htn_tile& T = out[i];
+        const Key k = mk(T.buf_c, (int32_t)(T.c_off & 0x7fffffff), (int32_t)(T.c_off >> 31), T.row0);
+        auto it = home.find(k);
+        int x;
+        if (it == home.end()) {
+            x = 0;
+            for (int j = 1; j < NX; ++j)
+                if (load[j] < load[x]) x = j;
+            home[k] = x;
+        } else
+            x = it->second;
+        // a strip much heavier than a fair share would serialise its XCD: overflow goes to the least loaded queue
+        if (load[x] > (total + 5 * (int64_t)out.size()) / NX) {
+            int y = 0;
+            for (int j = 1; j < NX; ++j)
+                if (load[j] < load[y]) y = j;
+            x = y;
+        }
+        q[x].push_back(i);
+        load[x] += cost(T);
+    }
+    std::vector<htn_tile> fin;
+    fin.reserve(out.size());
+    for (size_t r = 0; fin.size() < out.size(); ++r)
+        for (int x = 0; x < NX; ++x)
+            if (r < q[x].size()) fin.push_back(out[q[x][r]]);
+    t.tiles.swap(fin);
+    t.ntiles = (int32_t)t.tiles.size();
+    return ws;
+}
 
 // ---- y = H_eff x ----------------------------------------------------------------------------------
 void plan_apply(const Mpo& mpo, const ThetaLayout& tl, const EnvLayout& Ll, const EnvLayout& Rl, const MpoSite& W1,

@@ -34,6 +34,7 @@ class HipOps:
         self.arch = name.value.decode()
         self.cu_count = cus.value
         self._dots_scratch = None
+        self._ws = None              # split-K workspace of the kernel-level grouped_gemm wrapper (tickets | slabs)
         self._stream_ptr = None
         self.event_log = None        # bench.py: list of (start_event, end_event, tag, flops)
         h = C.c_void_p()
@@ -154,16 +155,33 @@ class HipOps:
         return C.c_void_p(0 if t is None else t.data_ptr())
 
     # ---- kernels ----------------------------------------------------------------------------
-    def upload_tasks(self, tasks):
-        """tasks: planner.Tasks -> (tiles_dev, ntiles, segs_dev)"""
-        tiles, segs = self.to_device_packed([tasks.tiles, tasks.segs])
-        return (tiles, tasks.ntiles, segs)
+    def upload_tasks(self, tasks, balance=False):
+        """tasks: Tasks (tests/ref_planner.py) -> (tiles_dev, ntiles, segs_dev).  balance=True applies the library's own
+        launch balancing pass (htn_balance_tiles: split-K parts for long tiles + XCD-aware order) and makes sure the
+        split-K workspace is large enough; grouped_gemm passes the workspace in buffer slot 7."""
+        tiles_h, ntiles = tasks.tiles, tasks.ntiles
+        if balance and ntiles > 0:
+            n_out = C.c_int32(0)
+            src = np.ascontiguousarray(tasks.tiles[:ntiles])
+            self.lib.htn_balance_tiles(src.ctypes.data, ntiles, self.cu_count, None, 0, C.byref(n_out))
+            out = np.zeros(max(n_out.value, 1), dtype=abi.TILE_DT)
+            slots = self.lib.htn_balance_tiles(src.ctypes.data, ntiles, self.cu_count, out.ctypes.data, len(out), C.byref(n_out))
+            if slots < 0:
+                raise abi.HtnError(self.lib.htn_last_error().decode())
+            tiles_h, ntiles = out, n_out.value
+            need = abi.WS_TICKET_ELEMS + slots * abi.HTN_TILE * abi.HTN_TILE
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = self.zeros_z(2 * need)
+        tiles, segs = self.to_device_packed([tiles_h, tasks.segs])
+        return (tiles, ntiles, segs)
 
     def grouped_gemm(self, bufs, dev_tasks, tag=None, flops=0):
         tiles, ntiles, segs = dev_tasks
         if ntiles == 0:
             return
         table = (C.c_void_p * abi.HTN_MAX_BUFS)(*[0 if b is None else b.data_ptr() for b in bufs])
+        if self._ws is not None and bufs[abi.BUF_WS] is None:
+            table[abi.BUF_WS] = self._ws.data_ptr()
         log = self.event_log is not None and tag is not None
         if log:      # HIP events on the launch stream (torch's current stream IS the launch stream)
             e0 = self.torch.cuda.Event(enable_timing=True)

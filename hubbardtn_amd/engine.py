@@ -255,6 +255,17 @@ class DMRG2:
         abi.check(self.lib, self.lib.htn_mps_get_env(self.handle, sd, b, flat.ctypes.data), "htn_mps_get_env")
         return flat[:n]
 
+    def env_bond(self, side, b) -> Bond:
+        """the bond table the environment on bond b was built on (left: last rightward update of that bond, right: last
+        leftward update -- a truncation by dimension may keep different counts in between)"""
+        sd = 0 if side == "L" else 1
+        n = self.lib.htn_mps_env_bond(self.handle, sd, b, None)
+        if n < 0:
+            raise abi.HtnError(f"environment {side} of bond {b} does not exist")
+        arr = np.zeros(max(n, 1), dtype=abi.SECTOR_DT)
+        self.lib.htn_mps_env_bond(self.handle, sd, b, arr.ctypes.data)
+        return Bond({(int(r["N"]), int(r["j"])): int(r["count"]) for r in arr[:n]})
+
     def download_env(self, side, b):
         """{(x, w, y): matrix}: left env keys (bra, w, ket) -> [n_bra, n_ket]; right env (ket, w, bra) -> [n_ket, n_bra]"""
         sd = 0 if side == "L" else 1

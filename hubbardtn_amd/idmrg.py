@@ -117,10 +117,11 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
             break
         # absorb the halves: environments at the centre bond become the new boundaries; the right block's bond is
         # relabelled N -> N + dNw (block order, hence the flat data, unchanged)
-        mid = eng.bond(T).dims
+        # (each environment carries the bond table it was built on: the left one dates from the rightward pass, the
+        # right one from the leftward pass, and truncdim may have kept different counts in between)
         Lenv, Renv = eng.env_data("L", T), eng.env_data("R", T)
-        bL = dict(mid)
-        bR = {(N + dNw, j): n for (N, j), n in mid.items()}
+        bL = dict(eng.env_bond("L", T).dims)
+        bR = {(N + dNw, j): n for (N, j), n in eng.env_bond("R", T).dims.items()}
     return IDMRGResult(energy_per_site=e_site, delta=delta, iterations=len(history), unit_cell=T,
                        bond_dims=eng.bond_dims(), spectrum=spec_prev, history=history, engine=eng, boundary=boundary)
 

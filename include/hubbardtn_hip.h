@@ -29,6 +29,9 @@ extern "C" {
 #define HTN_ABI_VERSION 2
 #define HTN_MAX_BUFS 8
 #define HTN_TILE 32              /* output tile edge of the grouped GEMM */
+#define HTN_GEMM_QUADS 4         /* wave-quads per workgroup of the grouped GEMM = K slabs (16 deep) a workgroup retires per
+                                    round (1024 threads, 96 KiB LDS, one workgroup per CU).  Measured alternative: 2 quads
+                                    (two co-resident 512-thread workgroups) is slower, 50 vs 38 us per chi=1024 apply */
 
 /* operand ops */
 #define HTN_OP_N 0               /* as stored                        */
@@ -50,7 +53,19 @@ typedef struct {
     int32_t row0, col0; /* tile origin inside the block                             */
     int32_t seg_begin, seg_count;
     int32_t pad[2];
-} htn_tile;             /* 48 bytes */
+    /* split-K across workgroups (nparts > 1; 0 or 1 = the record is the whole tile): this record is part `part` of
+     * `nparts` records that share one output tile and own consecutive ranges of its segment list (COPY segments in the
+     * last part).  The parts meet through bufs[HTN_BUF_WS]: int32 tickets[HTN_WS_TICKET_ELEMS * 4] (zero before the
+     * launch, reset by the kernel) followed by 32 x 32 complex128 slabs; the part drawing ticket nparts - 1 adds the
+     * slabs ws_slot .. ws_slot + nparts - 1 in part order and writes the tile. */
+    int32_t part, nparts;
+    int32_t ws_slot;    /* first slab of this tile                                   */
+    int32_t ticket;     /* index of this tile's ticket counter                       */
+} htn_tile;             /* 64 bytes */
+#define HTN_BUF_WS 7                 /* buffer-table slot of the split-K workspace   */
+#define HTN_WS_TICKET_ELEMS 4096     /* complex128 elements reserved for the tickets (64 KiB = 16384 counters) */
+/* workspace size in complex128 elements for a task list using n_slots slabs */
+#define HTN_WS_ELEMS(n_slots) (HTN_WS_TICKET_ELEMS + (int64_t)(n_slots) * HTN_TILE * HTN_TILE)
 
 /* One contribution  alpha * op(A)[block rows, 0:k] * op(B)[0:k, block cols]  to an output block.
  * op(A) is (block rows x k), op(B) is (k x block cols); offsets address element (0,0) of op(.). */
@@ -358,10 +373,21 @@ typedef struct {
     int64_t off;
 } htn_env_block;
 int32_t htn_mps_env_blocks(const htn_mps* mps, int32_t side, int32_t b, htn_env_block* blocks_host);
+/* the bond table an environment was built on.  It is the table of bond b AT THE TIME the environment was formed: the
+ * left environment of bond b dates from the last rightward update of that bond, the right one from the last leftward
+ * update, and a truncation by dimension may have kept different counts in between.  -> number of sectors */
+int32_t htn_mps_env_bond(const htn_mps* mps, int32_t side, int32_t b, htn_sector* sectors_host);
 /* planner introspection (tests): the task lists of the H_eff apply on bond i as the kernels receive them.
  * stage 0 = Z stage (may be empty), 1 = Y stage.  Returns counts through n_tiles / n_segs; tiles / segs may be NULL. */
 int htn_plan_apply_dump(htn_mps* mps, int32_t i, int32_t stage, int32_t* n_tiles, htn_tile* tiles_host, int32_t* n_segs,
                         htn_seg* segs_host, int64_t* z_size, int64_t* flops);
+/* the launch load-balancing pass the engine applies to every task list before upload (HIP backend): tiles with more K
+ * slabs than a CU's fair share are cut into split-K parts (htn_tile.part / nparts / ws_slot / ticket), records ordered
+ * longest first and dealt XCD-aware.  Returns the number of workspace slabs the balanced list needs (bufs[HTN_BUF_WS]
+ * must then hold HTN_WS_ELEMS(slabs) elements with the ticket region zeroed), -1 on error; *n_out = number of records
+ * (out may be NULL to query it). */
+int32_t htn_balance_tiles(const htn_tile* tiles_host, int32_t n_tiles, int32_t n_cus, htn_tile* out_host, int32_t out_cap,
+                          int32_t* n_out);
 /* plan-cache statistics: hits, misses (host planner invocations) */
 int htn_mps_cache_stats(const htn_mps* mps, int64_t* hits, int64_t* misses);
 

@@ -78,12 +78,16 @@ class NumpyOps:
                     b = self._op(B, int(s["b_off"]), int(s["ldb"]), int(s["op_b"]), k, n, 0, c0)
                     acc += alpha * (a @ b)
             outs.append((t, acc))
+        outs.sort(key=lambda ta: int(ta[0]["part"]) if int(ta[0]["nparts"]) > 1 else 0)      # part 0 writes first, the others add
         for t, acc in outs:      # write after all reads: tiles never alias their inputs anyway
             C = bufs[int(t["buf_c"])]
             m, n, r0, c0 = int(t["m"]), int(t["n"]), int(t["row0"]), int(t["col0"])
             i = (r0 + np.arange(m))[:, None]
             j = (c0 + np.arange(n))[None, :]
-            C[int(t["c_off"]) + i + j * int(t["ldc"])] = acc
+            if int(t["nparts"]) > 1 and int(t["part"]) > 0:      # split-K part: the parts of one tile add up
+                C[int(t["c_off"]) + i + j * int(t["ldc"])] += acc
+            else:
+                C[int(t["c_off"]) + i + j * int(t["ldc"])] = acc
 
     def dots(self, V, ldv, nvec, w, n, out):
         for i in range(nvec):

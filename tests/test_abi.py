@@ -46,7 +46,7 @@ def test_cpu_baseline_library_exports_the_engine_level_abi():
 
 
 def test_struct_layouts_match_header():
-    assert abi.TILE_DT.itemsize == 48 and abi.SEG_DT.itemsize == 64
+    assert abi.TILE_DT.itemsize == 64 and abi.SEG_DT.itemsize == 64
     assert abi.SVD_DT.itemsize == 40 and abi.COPY_DT.itemsize == 64
     assert ctypes.sizeof(abi.GemmLaunch) == 8 * 8 + 8 + 8 + 4 + 4
     assert abi.TILE_DT.fields["seg_begin"][1] == 32 and abi.SEG_DT.fields["alpha_re"][1] == 48

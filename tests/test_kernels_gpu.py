@@ -327,3 +327,35 @@ def test_lanczos_driver_matches_dense_eigh(hip_ops):
     x = hip_ops.to_host(V[0:n]).reshape(nc, m).T
     assert abs(np.linalg.norm(x) - 1) < 1e-12
     assert np.linalg.norm(H @ x - eig * x) < 1e-6
+
+
+@pytest.mark.parametrize("seed,nblocks,maxdim,maxk", [(5, 12, 70, 900), (6, 3, 140, 2500)])
+def test_grouped_gemm_split_k_across_workgroups_matches_numpy(hip_ops, seed, nblocks, maxdim, maxk):
+    """tiles with long K loops are cut into parts by the library's balancing pass (htn_balance_tiles): the parts run on
+    different workgroups / XCDs and meet through the ticket + slab workspace; the result must equal the numpy statement
+    of the UNSPLIT list, be bit-identical from launch to launch (parts are added in part order, whatever the arrival
+    order), and leave the tickets at zero"""
+    rng = np.random.default_rng(seed)
+    nel = 400_000
+    tasks, out_size = _random_tasks(rng, nblocks, maxdim, maxk, nel)
+    src0, src2 = _rand_z(rng, nel), _rand_z(rng, nel)
+    ref = np.zeros(out_size, dtype=np.complex128)
+    emu = NumpyOps()
+    emu.grouped_gemm([src0, ref, src2] + [None] * 5, emu.upload_tasks(tasks))
+    d0, d2 = hip_ops.to_device(src0), hip_ops.to_device(src2)
+    dev = hip_ops.upload_tasks(tasks, balance=True)
+    tiles_h = hip_ops.to_host(dev[0]).view(abi.TILE_DT)[:dev[1]]
+    assert dev[1] > tasks.ntiles and int(tiles_h["nparts"].max()) >= 2          # something was split
+    # the numpy emulator on the balanced list agrees with the unsplit statement (host-side check of the pass itself)
+    chk = np.zeros(out_size, dtype=np.complex128)
+    emu.grouped_gemm([src0, chk, src2] + [None] * 5, (tiles_h, dev[1], tasks.segs))
+    assert np.abs(chk - ref).max() <= 1e-12 * np.abs(ref).max()
+    outs = []
+    for _ in range(3):
+        out = hip_ops.zeros_z(out_size)
+        hip_ops.grouped_gemm([d0, out, d2] + [None] * 5, dev)
+        outs.append(hip_ops.to_host(out))
+    assert np.abs(outs[0] - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    tickets = hip_ops.to_host(hip_ops._ws)[:abi.WS_TICKET_ELEMS].view(np.int32)
+    assert not tickets.any()
