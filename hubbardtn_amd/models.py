@@ -45,17 +45,26 @@ SITE_OPS = {
     "S": (2, 0, _mat({(1, 1): sqrt(3.0) / 2})),
     "pair_dag": (0, +2, _mat({(2, 0): 1})),                         # c+_up c+_dn
     "pair": (0, -2, _mat({(0, 2): 1})),                             # c_dn c_up
+    # density-assisted ladder operators of the three-equal-index terms (C1, C2 at src:429-433): n_{-s} c+_s and n_{-s} c_s,
+    # i.e. c+ / c restricted to the (double <-> single) element
+    "cdag_d": (1, +1, _mat({(2, 1): -SQ2})),
+    "cdagF_d": (1, +1, _mat({(2, 1): SQ2})),
+    "c_d": (1, -1, _mat({(1, 2): 1})),
+    "Fc_d": (1, -1, _mat({(1, 2): -1})),
 }
 
 # two-site term kinds -> channels (name, (dN, k) carried by the virtual level, opening op, pass-through op,
 # closing op, closing factor).  Factors are fixed by the dense checks of tests/test_host_cpu.py:
 #   hop  : coef * sum_s (c+_{i s} c_{j s} + h.c.)      nn  : coef * n_i n_j
 #   ss   : coef * S_i . S_j                             pair: coef * (D+_i D_j + h.c.),  D = c_dn c_up
+#   dhopR: coef * sum_s n_{j,-s} (c+_{i s} c_{j s} + h.c.)   (density on the RIGHT site j > i)     dhopL: density on the left site
 TERM_CHANNELS = {
     "hop": (("hop+", (+1, 1), "cdagF", "F", "c", SQ2), ("hop-", (-1, 1), "Fc", "F", "cdag", -SQ2)),
     "nn": (("nn", (0, 0), "n", "id", "n", 1.0),),
     "ss": (("ss", (0, 2), "S", "id", "S", -sqrt(3.0)),),
     "pair": (("pair+", (+2, 0), "pair_dag", "id", "pair", 1.0), ("pair-", (-2, 0), "pair", "id", "pair_dag", 1.0)),
+    "dhopR": (("dR+", (+1, 1), "cdagF", "F", "c_d", SQ2), ("dR-", (-1, 1), "Fc", "F", "cdag_d", -SQ2)),
+    "dhopL": (("dL+", (+1, 1), "cdagF_d", "F", "c", SQ2), ("dL-", (-1, 1), "Fc_d", "F", "cdag", -SQ2)),
 }
 
 
@@ -213,13 +222,30 @@ def _exchange(pairs, i, j, J):
     pairs.append((i, j, "pair", J))
 
 
+def _assisted_hop(pairs, a, b, U):
+    """three-equal-index integral U_abbb (src:429-433, 452-458 one band; Uijjj_OS / Uijjj_IS src:617-649, 703-730):
+    D{a,b} = U sum_s n_{b,-s} (c+_{a s} c_{b s} + h.c.), density-assisted hopping with the density on orbital b.
+    The reference builds it as 0.5 U (C1 + C1' + C2 + C2') from two `cdc` factors under TensorKit's fermionic @tensor;
+    C1 and C2 are the two operator orderings of the same product (n_{b,-s} commutes with c_{b s}).  Sign and ordering
+    conventions of that contraction cannot be checked without the package, and the reference's tests never switch
+    U13 on (test/runtests.jl:45-48): parity of this term against the reference is UNPINNED; it is pinned against the
+    dense second-quantised form above (tests/test_host_cpu.py)."""
+    if U == 0.0 or a == b:
+        return
+    if a < b:
+        pairs.append((a, b, "dhopR", U))
+    else:
+        pairs.append((b, a, "dhopL", U))
+
+
 def hamiltonian(sim: Simulation, L: int):
     """Reduced open-chain MPO over L unit cells (L*B sites).  Returns list[MPOSite]."""
     if isinstance(sim, OB_Sim):
         if sim.period != 0:
             raise NotImplementedError("helix (period != 0) is outside the hot-path scope (SURVEY 8f)")
-        if sim.kwargs.get("U13", [0.0]) != [0.0]:
-            raise NotImplementedError("U13 terms are a 'next' row (SURVEY 8f.2)")
+        for key in ("JMs",):
+            if sim.kwargs.get(key, (0.0, 0.0))[1] != 0.0 and sim.kwargs.get("spin", False):
+                raise NotImplementedError("staggered field needs the spinful U(1)xU(1) mode (SURVEY 8f.2)")
         onsite = {s: [("docc", sim.u[0]), ("n", -sim.mu)] for s in range(L)}          # src:424
         pairs = []
         for r, tr in enumerate(sim.t, start=1):                                       # src:437-440
@@ -231,11 +257,13 @@ def hamiltonian(sim: Simulation, L: int):
         for r, Jr in enumerate(sim.J, start=1):                                       # src:445-451
             for i in range(L - r):
                 _exchange(pairs, i, i + r, Jr)
+        for r, Ur in enumerate(list(sim.kwargs.get("U13", [0.0])), start=1):        # src:452-458: 0.5 U13 (C1 + C2){i,j} + {j,i}
+            for i in range(L - r):
+                _assisted_hop(pairs, i, i + r, float(Ur))
+                _assisted_hop(pairs, i + r, i, float(Ur))
         return _build_mpo(L, onsite, pairs)
     if isinstance(sim, MB_Sim):
         B = sim.bands
-        if np.any(sim.U13 != 0.0):
-            raise NotImplementedError("multi-band U13 terms are a 'next' row (SURVEY 8f.2)")
         t, u, Jm = sim.t, sim.u, sim.J
         n = L * B
         site = lambda band, cell: band + cell * B                                     # InfiniteStrip(B, T*B), src:491
@@ -279,5 +307,21 @@ def hamiltonian(sim: Simulation, L: int):
                 for bi in range(B):
                     for bf in range(B):
                         _exchange(pairs, site(bi, cell), site(bf, cell + r), M[bi, bf])
+        for cell in range(L):                                                         # Uijjj_OS, src:617-649
+            for bi in range(B):
+                for bf in range(B):
+                    if bi != bf:
+                        _assisted_hop(pairs, site(bi, cell), site(bf, cell), float(sim.U13[bi, bf]))
+        U13_IS = sim.kwargs.get("U13_IS")                                             # Uijjj_IS, src:703-730: B x (B range) x 4
+        if U13_IS is not None:
+            U13_IS = np.asarray(U13_IS, dtype=float)
+            for r in range(1, U13_IS.shape[1] // B + 1):
+                M = U13_IS[:, B * (r - 1):B * r, :]
+                for cell in range(L - r):
+                    for bi in range(B):
+                        for bf in range(B):
+                            i, j = site(bi, cell), site(bf, cell + r)
+                            _assisted_hop(pairs, i, j, 0.5 * (M[bi, bf, 0] + M[bi, bf, 1]))      # density on j
+                            _assisted_hop(pairs, j, i, 0.5 * (M[bi, bf, 2] + M[bi, bf, 3]))      # density on i
         return _build_mpo(n, onsite, pairs)
     raise TypeError(f"unsupported simulation type {type(sim)}")

@@ -10,8 +10,8 @@ File CONTAINER: the reference writes JLD2 (an HDF5 dialect); neither JLD2 nor HD
 image, so the same dictionaries are stored as NumPy .npz archives (names end in .npz instead of .jld2).  Directory
 layout, prefixes and the DrWatson `savename` rule (fields of type Real / String sorted by name, 3 significant digits)
 follow the reference; byte-level interchange with Julia needs an HDF5 writer and is NOT claimed.
-Site tensors are stored in this library's Euclidean ("tilde") normalisation; `to_tensorkit=True` rescales every
-sub-block by sqrt((2S_l+1)/(2S_r+1))^-1 ... see INTEGRATION.md for the one-real-factor-per-block conversion.
+Site tensors are stored in this library's Euclidean ("tilde") normalisation; INTEGRATION.md section 2 gives the
+one-real-factor-per-block conversion to TensorKit's reduced data.
 """
 from __future__ import annotations
 
@@ -132,6 +132,8 @@ def produce_or_load(compute, simul, force=False, directory=None, **kw):
     if kw.get("L") and not simul.kwargs.get("L"):
         simul.kwargs["L"] = kw["L"]
     sub, stem = cache_name(simul)
+    if kw.get("chi"):                                     # fixed-D runs (not in the reference) are separate entries
+        stem += f"_chi={int(kw['chi'])}"
     directory = directory or datadir("sims", sub)
     entry = os.path.join(directory, stem)
     if os.path.isdir(entry) and not force:

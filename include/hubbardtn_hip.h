@@ -212,7 +212,7 @@ int htn_batched_copy_z(void* dst, const void* src, const int32_t* idx, const dou
  *     (left level, right level, site-operator id, coefficient) entries; site operators as reduced matrix elements;
  *   - the MPS as TensorKit-shaped data: one flat ComplexF64 vector per site + a table of sub-blocks
  *     (left sector, site multiplet, right sector, offset, leading dimension) -- TensorKit's per-fusion-tree views --
- *     and per bond the int32 sector labels (N, 2S) with their int64... (here int32) multiplet counts.
+ *     and per bond the int32 sector labels (N, 2S) with their int32 multiplet counts (htn_sector).
  * Everything below that -- sector layouts, recoupling coefficients (closed-form 9j), task lists, theta formation,
  * Lanczos, per-sector SVD, the global truncation rule, write-back, environment transfer, the sweep loop -- runs
  * inside the library (C++ planner + HIP kernels; one host thread per context).
@@ -364,8 +364,7 @@ int64_t htn_mps_site_size(const htn_mps* mps, int32_t i, int32_t* kind_host);   
 int32_t htn_mps_get_site(const htn_mps* mps, int32_t i, htn_subblock* subs_host, void* data_host);  /* -> #sub-blocks */
 int64_t htn_mps_env_size(const htn_mps* mps, int32_t side, int32_t b);                      /* side 0 = left, 1 = right */
 int htn_mps_get_env(const htn_mps* mps, int32_t side, int32_t b, void* data_host);
-/* block table of an environment: per block (bra N, bra j, level, ket N, ket j, offset lo, offset hi32 = 0, rows, cols)
- * as 9 int32... use htn_env_block */
+/* block table of an environment (htn_mps_env_blocks): one record per stored block */
 typedef struct {
     int32_t aN, aj, w, bN, bj;     /* left env: (bra, w, ket) stored [n_bra x n_ket]; right env: (ket, w, bra) [n_ket x n_bra] */
     int32_t rows, cols;

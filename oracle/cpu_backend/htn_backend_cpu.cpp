@@ -236,10 +236,20 @@ struct CpuBackend : Backend {
         return 0;
     }
 
+    // fixed chunking + ordered final sum: bit-reproducible whatever the thread count (replicated ranks of the sharded
+    // apply must take identical truncation decisions)
     static double nrm2(const cplx* x, int64_t n) {
+        const int64_t chunk = 4096, nch = (n + chunk - 1) / chunk;
+        std::vector<double> part((size_t)nch, 0.0);
+#pragma omp parallel for schedule(static)
+        for (int64_t c = 0; c < nch; ++c) {
+            double s = 0.0;
+            const int64_t hi = std::min(n, (c + 1) * chunk);
+            for (int64_t i = c * chunk; i < hi; ++i) s += std::norm(x[i]);
+            part[(size_t)c] = s;
+        }
         double s = 0.0;
-#pragma omp parallel for reduction(+ : s)
-        for (int64_t i = 0; i < n; ++i) s += std::norm(x[i]);
+        for (double v : part) s += v;
         return s;
     }
 

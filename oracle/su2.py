@@ -170,6 +170,12 @@ def site_operators():
     ops["S"] = (2, 0, reduce_site_operator([-sp / np.sqrt(2.0), sz, sp.T / np.sqrt(2.0)], 2))
     ops["pair_dag"] = (0, +2, reduce_site_operator([a_up.T @ a_dn.T], 0))       # c+_up c+_dn
     ops["pair"] = (0, -2, reduce_site_operator([a_dn @ a_up], 0))               # c_dn c_up
+    # density-assisted ladder operators n_{-s} c+_s / n_{-s} c_s of the three-equal-index terms (src:429-433, 452-458)
+    n_up, n_dn = a_up.T @ a_up, a_dn.T @ a_dn
+    ops["cdag_d"] = (1, +1, reduce_site_operator([n_dn @ a_up.T, n_up @ a_dn.T], 1))
+    ops["cdagF_d"] = (1, +1, reduce_site_operator([n_dn @ a_up.T @ F, n_up @ a_dn.T @ F], 1))
+    ops["c_d"] = (1, -1, reduce_site_operator([-n_up @ a_dn, n_dn @ a_up], 1))
+    ops["Fc_d"] = (1, -1, reduce_site_operator([-F @ n_up @ a_dn, F @ n_dn @ a_up], 1))
     return ops
 
 

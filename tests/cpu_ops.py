@@ -26,6 +26,9 @@ class CpuOps:
         abi.check(self.lib, self.lib.htn_ctx_create(abi.BACKEND_CPU, 0, None, C.byref(h)), "htn_ctx_create")
         self.ctx = h
         self._cb = None
+        # small test problems: a few OpenMP threads are plenty, and a wide team spinning at barriers thrashes when the
+        # test machine runs other jobs (bench.py's cpu_baseline sets the team to the host's core share itself)
+        self.lib.htn_cpu_set_threads(min(4, os.cpu_count() or 1))
 
     def set_threads(self, n):
         """OpenMP team size of the host kernels; returns the previous setting"""

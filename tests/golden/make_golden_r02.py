@@ -88,7 +88,7 @@ def oracle_vs_reference_constants():
             eng = dmrg_su2.DMRG2(psi, ompo.hubbard_mpo(L, rec["t"], rec["u"]), chi_full=16, lanczos_tol=1e-6)
             # state preparation (fixed D, loose eigensolver): two-site DMRG from a random state spreads charge slowly at
             # strong coupling / low density, so many cheap sweeps come first
-            for chi, nsw in ((8, 16), (16, 12), (32, 4)):
+            for chi, nsw in ((8, 16), (16, 12), (32, 10)):
                 eng.chi_full = chi
                 for _ in range(nsw):
                     E, _ = eng.sweep()

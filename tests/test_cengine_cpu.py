@@ -120,6 +120,8 @@ def test_cxx_engine_other_models_and_fillings_match_oracle(cpu_ops):
     _generic_oracle_vs_cxx(cpu_ops, H, 8, (12, 0), 40, 2, 5)
     _generic_oracle_vs_cxx(cpu_ops, H, 8, (7, 1), 40, 2, 5)
     _generic_oracle_vs_cxx(cpu_ops, H, 8, (8, 0), None, 2, 5, cutoff=1e-2)
+    # three-equal-index terms (U13, src:452-458): restricted ladder operators on hop-type MPO levels
+    _generic_oracle_vs_cxx(cpu_ops, models.hamiltonian(models.OB_Sim([1.0, 0.2], [4.0], 0.0, 1, 1, U13=[0.3, 0.1]), 8), 8, (8, 0), 40, 2, 5)
 
 
 def test_cxx_engine_untruncated_equals_exact_diagonalisation_and_heff_is_hermitian(cpu_ops):

@@ -147,6 +147,11 @@ def test_exchange_and_polyacetylene_models_match_oracle(hip_ops):
     J = np.array([[0.000, 0.123, 0.000, 0.000], [0.123, 0.000, 0.113, 0.000]])
     H = models.hamiltonian(models.MB_Sim(t, U, J, 1, 1, 2.5, 20), 4)
     _generic_oracle_vs_hip(hip_ops, H, 8, (8, 0), 40, 2, 5)
+    # three-equal-index terms (U13 one band, U13_OS two bands): density-assisted hopping channels
+    H = models.hamiltonian(models.OB_Sim([1.0, 0.2], [4.0], 0.0, 1, 1, U13=[0.3, 0.1]), 8)
+    _generic_oracle_vs_hip(hip_ops, H, 8, (8, 0), 40, 2, 5)
+    H = models.hamiltonian(models.MB_Sim(t, U, J, np.array([[0.0, 0.4], [0.4, 0.0]]), 1, 1, 2.5, 20), 4)
+    _generic_oracle_vs_hip(hip_ops, H, 8, (8, 0), 40, 2, 5)
 
 
 def test_runs_are_bit_reproducible(hip_ops):

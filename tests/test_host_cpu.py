@@ -334,3 +334,73 @@ def test_symbolic_environment_plans_equal_loop_plans():
     for trial in range(3):                      # same sector sets, different multiplicities: the cached structure is reused
         pert = lambda n: max(1, int(n + rng.integers(-2, 3)))
         check(pl.Bond({k: pert(v) for k, v in base0.items()}), pl.Bond({k: pert(v) for k, v in base1.items()}), mpo[11])
+
+
+def _dense_with_u13(L, t, u, mu, pairs_u13):
+    """ed.dense_hamiltonian + sum over (a, b, U): U sum_s n_{b,-s} (c+_{a s} c_{b s} + h.c.)  (Jordan-Wigner matrices)"""
+    from oracle import su2
+    lm = su2.local_matrices()
+
+    def site_op(mats):
+        out = np.eye(1)
+        for s in range(L):
+            out = np.kron(out, mats.get(s, lm["id"]))
+        return out
+
+    def c_op(i, spin):
+        mats = {s: lm["F"] for s in range(i)}
+        mats[i] = lm["a_up"] if spin == 0 else lm["a_dn"]
+        return site_op(mats)
+    c = {(i, s): c_op(i, s) for i in range(L) for s in (0, 1)}
+    H = ed.dense_hamiltonian(L, t, u, mu)
+    for (a, b, U) in pairs_u13:
+        for s in (0, 1):
+            hop = c[(a, s)].T @ c[(b, s)]
+            H = H + U * (c[(b, 1 - s)].T @ c[(b, 1 - s)]) @ (hop + hop.T)
+    return H
+
+
+def test_three_equal_index_terms_equal_dense_density_assisted_hopping():
+    """U13 of OB_Sim (src:452-458) and Uijjj_OS / Uijjj_IS of MB_Sim (src:617-649, 703-730): the MPO equals the dense
+    sum_s n_{b,-s}(c+_{a s} c_{b s} + h.c.) form; reduced elements of the density-assisted ladder operators equal the
+    oracle's Wigner-Eckart reduction of their Jordan-Wigner matrices.  (The reference's tests never switch these terms
+    on: parity against the reference itself is unpinned, models._assisted_hop.)"""
+    from oracle import su2
+    ops = su2.site_operators()
+    for name in ("cdag_d", "cdagF_d", "c_d", "Fc_d"):
+        k, dN, red = ops[name]
+        k2, dN2, red2 = models.SITE_OPS[name]
+        assert (k, dN) == (k2, dN2) and np.abs(red - red2).max() < 1e-14
+    L, t, u, U13 = 4, [1.0, 0.2], [4.0, 0.5], [0.3, 0.1]
+    M = ompo.mpo_to_dense(_as_dict(models.hamiltonian(models.OB_Sim(t, u, 0.1, 1, 1, U13=U13), L)))
+    pairs = [(i, i + r, Ur) for r, Ur in enumerate(U13, start=1) for i in range(L - r)]
+    pairs += [(b, a, U) for (a, b, U) in pairs]
+    H = _dense_with_u13(L, t, u, 0.1, pairs)
+    assert np.abs(M - H).max() < 1e-12 and np.abs(M - M.T).max() < 1e-13
+    # two bands, two cells: on-site inter-band U13_OS (ordered pairs, density on the second index) and inter-cell U13_IS
+    B, cells = 2, 2
+    tm = np.array([[0.1, 0.7, 0.4, 0.0], [0.7, -0.2, 0.3, 0.2]])
+    um = np.array([[3.0, 1.0, 0.0, 0.0], [1.0, 2.5, 0.0, 0.0]])
+    U13_OS = np.array([[0.0, 0.25], [-0.15, 0.0]])
+    U13_IS = np.zeros((B, B, 4))
+    U13_IS[0, 1] = [0.2, 0.1, -0.3, 0.05]
+    U13_IS[1, 1] = [0.4, 0.0, 0.0, 0.2]
+    sim = models.MB_Sim(tm, um, np.zeros((B, 2 * B)), U13_OS, 1, 1, 2.0, 8, U13_IS=U13_IS)
+    M = ompo.mpo_to_dense(_as_dict(models.hamiltonian(sim, cells)))
+    site = lambda b, c: b + c * B
+    n = B * cells
+    # reference Hamiltonian without the three-index terms, from the same builder (already pinned densely elsewhere)
+    M0 = ompo.mpo_to_dense(_as_dict(models.hamiltonian(models.MB_Sim(tm, um, np.zeros((B, 2 * B)), 1, 1, 2.0, 8), cells)))
+    pairs = []
+    for c_ in range(cells):
+        for bi in range(B):
+            for bf in range(B):
+                if bi != bf:
+                    pairs.append((site(bi, c_), site(bf, c_), U13_OS[bi, bf]))
+    for bi in range(B):
+        for bf in range(B):
+            i, j = site(bi, 0), site(bf, 1)
+            pairs.append((i, j, 0.5 * (U13_IS[bi, bf, 0] + U13_IS[bi, bf, 1])))
+            pairs.append((j, i, 0.5 * (U13_IS[bi, bf, 2] + U13_IS[bi, bf, 3])))
+    D = _dense_with_u13(n, [0.0], [0.0], 0.0, pairs)
+    assert np.abs((M - M0) - D).max() < 1e-12

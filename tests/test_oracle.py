@@ -105,3 +105,38 @@ def test_truncation_rules():
     assert keep2 == {(4, 0): 2, (4, 2): 1, (3, 1): 1}
     keep3, _ = dmrg_su2.truncate_spectrum(sv, chi_full=1000)
     assert keep3 == {(4, 0): 3, (4, 2): 2, (3, 1): 1}
+
+
+def test_oracle_is_pinned_by_the_reference_test_constants():
+    """the ORACLE itself (oracle/dmrg_su2.DMRG2, not the product) against every one-band record of
+    tests/golden/reference_constants.json (data of /root/reference/test/OB.jl:15-54) at the reference's own atol.
+    The oracle runs (finite chains of 24 and 32 sites at filling P/Q with the reference's truncation
+    truncbelow(10^-svalue), energy density from the difference) take minutes on one core, so they are generated by the
+    committed script tests/golden/make_golden_r02.py ("oracle_vs_reference_constants") into golden_r02.json; here the
+    fixture is compared with the reference's numbers, and one oracle run is repeated live to show that the fixture is
+    what the oracle computes."""
+    import json
+    import os
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_constants.json")))
+    fix = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_r02.json")))["oracle_vs_reference_constants"]
+    recs = ref["OB_parameters"] + ref["OB_filling"]
+    assert len(fix) == len(recs) == 6
+    for f, r in zip(fix, recs):
+        assert (f["u"], f["P"], f["Q"]) == (r["u"], r["P"], r["Q"]) and f["E_per_site_reference"] == r["E_per_site"]
+        e = (f["E_oracle"][1] - f["E_oracle"][0]) / (f["L"][1] - f["L"][0])
+        assert abs(e - f["e_density_oracle"]) < 1e-14
+        assert abs(e - r["E_per_site"]) < r["atol"], (f["u"], f["P"], f["Q"], e)          # the reference's own tolerance (1e-2)
+        assert abs(e - r["E_per_site"]) < 5e-4                                               # what the shared truncation rule gives
+    # live: the smallest case again (U = 0, L = 24), same schedule as the generator
+    f = fix[0]
+    L = f["L"][0]
+    psi = dmrg_su2.random_mps(L, (L * f["P"] // f["Q"], 0), 6, seed=5)
+    eng = dmrg_su2.DMRG2(psi, ompo.hubbard_mpo(L, f["t"], f["u"]), chi_full=8, lanczos_tol=1e-6)
+    for chi, nsw in ((8, 16), (16, 12), (32, 10)):
+        eng.chi_full = chi
+        for _ in range(nsw):
+            E, _ = eng.sweep()
+    eng.chi_full, eng.cutoff, eng.lanczos_tol = None, 10.0 ** -f["svalue"], 1e-10
+    for _ in range(3):
+        E, _ = eng.sweep()
+    assert abs(E - f["E_oracle"][0]) < 1e-8 * abs(E)
