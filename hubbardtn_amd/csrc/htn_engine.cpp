@@ -92,6 +92,10 @@ struct EnvC {
 struct SvdC {
     SvdPlan sp;
     DBufP stage, desc;
+    // sector-sharded SVD (world > 1): the blocks this rank owns (LPT over ~ m n^2), as their own staging / descriptor lists
+    std::vector<htn_svd_block> own_desc;
+    DBufP own_stage, own_desc_dev;
+    int n_own = 0;
 };
 struct FinC {
     SiteLayoutP layA, layB;
@@ -364,6 +368,34 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
         if (!s->stage || !s->desc) return nullptr;
         if (be->upload(s->stage->p, s->sp.stage.data(), sizeof(htn_copy_item) * s->sp.stage.size())) return nullptr;
         if (be->upload(s->desc->p, s->sp.desc.data(), sizeof(htn_svd_block) * s->sp.desc.size())) return nullptr;
+        if (ctx->world > 1) {
+            // owner of every block: longest first onto the least loaded rank (deterministic: every rank computes the same map)
+            const int nbk = (int)s->sp.mids.size();
+            std::vector<int> ord(nbk);
+            for (int b = 0; b < nbk; ++b) ord[b] = b;
+            auto cost = [&](int b) { return (double)s->sp.desc[b].m * s->sp.desc[b].n * s->sp.desc[b].n; };
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return cost(a) > cost(b); });
+            std::vector<double> load(ctx->world, 0.0);
+            std::vector<htn_copy_item> st_own;
+            for (int b : ord) {
+                int r = 0;
+                for (int q = 1; q < ctx->world; ++q)
+                    if (load[q] < load[r]) r = q;
+                load[r] += cost(b);
+                if (r == ctx->rank) {
+                    s->own_desc.push_back(s->sp.desc[b]);
+                    st_own.push_back(s->sp.stage[b]);
+                }
+            }
+            s->n_own = (int)s->own_desc.size();
+            if (s->n_own) {
+                s->own_stage = dalloc(sizeof(htn_copy_item) * st_own.size());
+                s->own_desc_dev = dalloc(sizeof(htn_svd_block) * s->own_desc.size());
+                if (!s->own_stage || !s->own_desc_dev) return nullptr;
+                if (be->upload(s->own_stage->p, st_own.data(), sizeof(htn_copy_item) * st_own.size())) return nullptr;
+                if (be->upload(s->own_desc_dev->p, s->own_desc.data(), sizeof(htn_svd_block) * s->own_desc.size())) return nullptr;
+            }
+        }
         return s;
     });
     if (!sc) return 1;
@@ -371,11 +403,21 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
     const int nb = (int)sp.mids.size();
     DView G = zalloc(sp.g_size, false), Vj = zalloc(sp.v_size, false);
     // singular values and per-block sweep counts share one buffer: ONE device-to-host copy (one stream sync) per bond
-    const size_t s_elems = (size_t)std::max<int64_t>(sp.s_size, 1), i_elems = (size_t)std::max(nb, 1);
+    const size_t s_elems = ((size_t)std::max<int64_t>(sp.s_size, 1) + 1) & ~(size_t)1, i_elems = (size_t)std::max(nb, 1);
     DBufP S = dalloc(sizeof(double) * s_elems + sizeof(int32_t) * i_elems);
     if (!G.base || !Vj.base || !S) return set_error("device allocation failed (SVD workspace)");
     int32_t* info_dev = (int32_t*)((double*)S->p + s_elems);
-    if (be->batched_copy(G.ptr(), x, nullptr, nullptr, (const htn_copy_item*)sc->stage->p, nb, 1.0)) return 1;
+    // Sector-sharded SVD (world > 1): every rank stages and decomposes only the blocks it owns; everything else
+    // in G / S (and the rotation workspace of accumulate-mode blocks) stays zero and ONE sum over ranks per buffer
+    // hands every rank the complete result -- bit-identical everywhere (x + 0 + ... + 0), so the ranks stay in lock step.
+    const bool svd_shard = ctx->world > 1 && ctx->shard;
+    if (svd_shard) {
+        if (be->zero(G.ptr(), sizeof(cplx) * (size_t)std::max<int64_t>(sp.g_size, 1))) return 1;
+        if (be->zero(S->p, sizeof(double) * s_elems + sizeof(int32_t) * i_elems)) return 1;
+        if (sp.any_accumulate && be->zero(Vj.ptr(), sizeof(cplx) * (size_t)std::max<int64_t>(sp.v_size, 1))) return 1;
+        if (sc->n_own && be->batched_copy(G.ptr(), x, nullptr, nullptr, (const htn_copy_item*)sc->own_stage->p, sc->n_own, 1.0)) return 1;
+    } else if (be->batched_copy(G.ptr(), x, nullptr, nullptr, (const htn_copy_item*)sc->stage->p, nb, 1.0))
+        return 1;
     // Singular directions far below what the truncation keeps need not be resolved (optional, OFF by default).
     // truncbelow(eta): everything below eta goes anyway.  truncdim(D): if the previous update of this bond (same D) was
     // limited by D, its smallest kept value is where the cut will fall again.  x is normalised: values compare across sweeps.
@@ -390,15 +432,23 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
             cut = o.rank_cut * h->second.second;
         so.rank_cut = std::max(cut, o.rank_cut * o.cutoff);
     }
-    if (be->jacobi_svd(G.ptr(), Vj.ptr(), (double*)S->p, (const htn_svd_block*)sc->desc->p, sp.desc.data(), nb, sp.max_m,
-                       o.jacobi_max_sweeps > 0 ? o.jacobi_max_sweeps : 40, o.jacobi_tol > 0.0 ? o.jacobi_tol : 1e-14,
-                       info_dev, &so))
+    if (svd_shard) {
+        if (sc->n_own && be->jacobi_svd(G.ptr(), Vj.ptr(), (double*)S->p, (const htn_svd_block*)sc->own_desc_dev->p,
+                                        sc->own_desc.data(), sc->n_own, sp.max_m, o.jacobi_max_sweeps > 0 ? o.jacobi_max_sweeps : 40,
+                                        o.jacobi_tol > 0.0 ? o.jacobi_tol : 1e-14, info_dev, &so))
+            return 1;
+        if (exchange_tramp(G.ptr(), std::max<int64_t>(sp.g_size, 1), ctx)) return set_error("sharded SVD: exchange of the blocks failed");
+        if (exchange_tramp(S->p, (int64_t)(s_elems / 2), ctx)) return set_error("sharded SVD: exchange of the singular values failed");
+        if (sp.any_accumulate && exchange_tramp(Vj.ptr(), std::max<int64_t>(sp.v_size, 1), ctx)) return 1;
+    } else if (be->jacobi_svd(G.ptr(), Vj.ptr(), (double*)S->p, (const htn_svd_block*)sc->desc->p, sp.desc.data(), nb, sp.max_m,
+                              o.jacobi_max_sweeps > 0 ? o.jacobi_max_sweeps : 40, o.jacobi_tol > 0.0 ? o.jacobi_tol : 1e-14,
+                              info_dev, &so))
         return 1;
     std::vector<double> s_host(s_elems + (i_elems + 1) / 2);
     if (be->download(s_host.data(), S->p, sizeof(double) * s_elems + sizeof(int32_t) * i_elems)) return 1;
     const int32_t* info_h = (const int32_t*)(s_host.data() + s_elems);
     int jac_sweeps = 0;
-    for (int b = 0; b < nb; ++b) {
+    for (int b = 0; b < (svd_shard ? sc->n_own : nb); ++b) {        // (sharded: the counts of this rank's own blocks)
         if (info_h[b] < 0) return set_error("Jacobi SVD did not converge (bond %d, block %d, %d sweeps)", i + 1, b, -info_h[b]);
         jac_sweeps = std::max(jac_sweeps, (int)info_h[b]);
     }
