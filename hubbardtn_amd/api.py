@@ -125,16 +125,20 @@ def hamiltonian(simul: Simulation, L: int | None = None):
 
 
 def initialize_mps(H, P: int, max_dimension: int, spin: bool = False, Q: int = 1, seed: int = 1234, ops=None):
-    """random right-canonical start with per-sector cap `max_dimension` (src:917-959)"""
-    if spin:
-        raise NotImplementedError("U(1)xU(1) spinful mode is a 'next' row (SURVEY 8f.2)")
+    """random right-canonical start with per-sector cap `max_dimension` (src:917-959); the symmetry mode (SU(2) x U(1),
+    or U(1) x U(1) for `spin=true`) is the Hamiltonian's"""
     if isinstance(H, InfiniteHamiltonian):
+        if bool(spin) != (not models.symmetry_of(H.simul).su2):
+            raise ValueError("initialize_mps: `spin` does not match the Hamiltonian's symmetry mode")
         return InfiniteMPS(int(max_dimension), seed, ops)
     nsites = len(H)
+    sym = getattr(H, "sym", models.SU2U1)
+    if bool(spin) != (not sym.su2):
+        raise ValueError("initialize_mps: `spin` does not match the Hamiltonian's symmetry mode")
     if (nsites * P) % Q:
         raise ValueError("filling P/Q incompatible with the chain length")
-    target = (nsites * P // Q, 0)
-    bonds, tensors = mps.random_mps(nsites, target, max_dimension, seed=seed)
+    target = (nsites * P // Q, 0)                     # total spin 0 / total Sz 0
+    bonds, tensors = mps.random_mps(nsites, target, max_dimension, seed=seed, sym=sym)
     eng = _engine.DMRG2(ops or _ops(), H, bonds, tensors)
     return FiniteMPS(eng, nsites)
 
@@ -292,6 +296,29 @@ def density_state(psi):
         n, _ = psi.result.engine.site_occupations()
         return n[T // 2:T // 2 + T]
     return psi.engine.site_occupations()[0]
+
+
+def density_spin(psi):
+    """(n_up, n_dn) per site (src:1412-1456): spinful U(1) x U(1) mode only -- the SU(2) mode raises the reference's
+    "This system is spin independent." -- finite chain: all sites, infinite chain: the unit cell"""
+    if isinstance(psi, InfiniteMPS):
+        if psi.result is None:
+            raise RuntimeError("run find_groundstate first")
+        T = psi.result.unit_cell
+        up, dn = psi.result.engine.spin_occupations()
+        return up[T // 2:T // 2 + T], dn[T // 2:T // 2 + T]
+    return psi.engine.spin_occupations()
+
+
+def calc_ms(psi):
+    """staggered magnetisation |<n_up - n_dn>| of the first site (src:1458-1473; warns like the reference when the
+    magnitude is not uniform)"""
+    import warnings
+    up, dn = density_spin(psi)
+    mag = up - dn
+    if not np.allclose(np.abs(mag), abs(mag[0]), rtol=1e-6, atol=1e-12):
+        warnings.warn("Spin-density wave?")
+    return float(abs(mag[0]))
 
 
 def double_occupancy(psi):

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import abi
-from .models import SITE_MULT, SITE_OPS
+from .models import SU2U1
 from .sectors import Bond
 
 
@@ -48,10 +48,12 @@ def _stats(rec) -> BondStats:
 
 
 class CMpo:
-    """htn_mpo handle built from a list of models.MPOSite (reduced SU(2) x U(1) x fZ2 operators)"""
+    """htn_mpo handle built from a models.MPO (list of MPOSite + symmetry; a plain list means SU(2) x U(1) x fZ2)"""
 
     def __init__(self, ops, sites):
         self.ops, self.lib = ops, ops.lib
+        self.sym = msym = getattr(sites, "sym", SU2U1)
+        SITE_MULT, SITE_OPS = msym.site_mult, msym.site_ops
         names = sorted({e[2] for s in sites for e in s.entries})
         self.op_index = {n: k for k, n in enumerate(names)}
         optab = np.zeros(max(len(names), 1), dtype=abi.SITE_OP_DT)
@@ -79,7 +81,7 @@ class CMpo:
                 q += 1
             entry_ptr.append(q)
         sym = abi.Symmetry()
-        sym.kind, sym.n_site = abi.SYM_SU2_U1, len(SITE_MULT)
+        sym.kind, sym.n_site = msym.kind, len(SITE_MULT)
         for s, (N, j) in enumerate(SITE_MULT):
             sym.site_N[s], sym.site_j[s] = N, j
         lv = np.ascontiguousarray(np.array(levels, dtype=np.int32).reshape(-1, 2))
@@ -117,6 +119,7 @@ class DMRG2:
         self.ops, self.lib = ops, ops.lib
         self.cmpo = mpo if isinstance(mpo, CMpo) else CMpo(ops, mpo)
         self.mpo = self.cmpo.sites
+        self.sym = self.cmpo.sym
         self.L = len(self.mpo)
         self.chi_full, self.cutoff, self.weighting = chi_full, cutoff, weighting
         self.krylovdim, self.lanczos_tol, self.maxrestart = krylovdim, lanczos_tol, maxrestart
@@ -189,7 +192,7 @@ class DMRG2:
         n = self.lib.htn_mps_bond(self.handle, b, None)
         arr = np.zeros(max(n, 1), dtype=abi.SECTOR_DT)
         self.lib.htn_mps_bond(self.handle, b, arr.ctypes.data)
-        return Bond({(int(r["N"]), int(r["j"])): int(r["count"]) for r in arr[:n]})
+        return Bond({(int(r["N"]), int(r["j"])): int(r["count"]) for r in arr[:n]}, self.sym)
 
     def bond_dims(self):
         """`dim_state` analogue (src/HubbardFunctions.jl:1399-1405): TensorKit dim of each bond"""
@@ -264,7 +267,7 @@ class DMRG2:
             raise abi.HtnError(f"environment {side} of bond {b} does not exist")
         arr = np.zeros(max(n, 1), dtype=abi.SECTOR_DT)
         self.lib.htn_mps_env_bond(self.handle, sd, b, arr.ctypes.data)
-        return Bond({(int(r["N"]), int(r["j"])): int(r["count"]) for r in arr[:n]})
+        return Bond({(int(r["N"]), int(r["j"])): int(r["count"]) for r in arr[:n]}, self.sym)
 
     def download_env(self, side, b):
         """{(x, w, y): matrix}: left env keys (bra, w, ket) -> [n_bra, n_ket]; right env (ket, w, bra) -> [n_ket, n_bra]"""
@@ -347,27 +350,39 @@ class DMRG2:
         self.energy = E.value
         return self.energy
 
-    def site_occupations(self):
-        """-> (n, d): <n_i> and the double occupancy <n_up n_dn>_i of every site (density_state, src:1495-1523).
-        Call after sweep() (centre on site 0, sites >= 1 right-canonical).  The centre is carried through the chain
-        without optimisation; with the centre on site i the probability of site multiplet s is the squared norm
-        of the (., s, .) blocks (tilde normalisation), and n = P(single) + 2 P(double).  Leaves stats/energy alone."""
+    def site_probabilities(self):
+        """-> P[L, n_site]: probability of every site multiplet on every site.  Call after sweep() (centre on site 0,
+        sites >= 1 right-canonical).  The centre is carried through the chain without optimisation; with the centre on
+        site i the probability of site multiplet s is the squared norm of the (., s, .) blocks (tilde normalisation).
+        Leaves stats/energy alone."""
         L = self.L
-        n, d = np.zeros(L), np.zeros(L)
+        P = np.zeros((L, self.sym.n_site))
 
         def read(i):
-            p = np.zeros(3)
+            p = np.zeros(self.sym.n_site)
             for (l, s, r), blk in self.download_site(i).items():
                 p[s] += float(np.sum(np.abs(blk) ** 2))
-            p /= p.sum()
-            n[i], d[i] = p[1] + 2.0 * p[2], p[2]
+            P[i] = p / p.sum()
         read(0)
         for i in range(L - 1):          # moving the centre must not truncate by value: cutoff 0
             self.update_bond(i, +1, "right", optimise=False, record=False, cutoff=0.0)
             read(i + 1)
         for i in range(L - 2, -1, -1):  # back to the post-sweep convention
             self.update_bond(i, -1, "left", optimise=False, record=False, cutoff=0.0)
-        return n, d
+        return P
+
+    def site_occupations(self):
+        """-> (n, d): <n_i> and the double occupancy <n_up n_dn>_i of every site (density_state, src:1495-1523)"""
+        P = self.site_probabilities()
+        Ns = np.array([m[0] for m in self.sym.site_mult], dtype=float)          # electrons of every site multiplet
+        return P @ Ns, P[:, -1].copy()                                            # (the last multiplet is the doubly occupied one)
+
+    def spin_occupations(self):
+        """-> (n_up, n_dn) per site; spinful U(1) x U(1) mode only (density_spin, src:1412-1456)"""
+        if self.sym.su2:
+            raise ValueError("This system is spin independent.")                # the reference's error text (src:1424)
+        P = self.site_probabilities()
+        return P[:, 1] + P[:, 3], P[:, 2] + P[:, 3]
 
     def bond_energies(self):
         """<psi| H |psi> of the state AS STORED (truncated), evaluated by a non-optimising pass: returns (E_total,
@@ -413,7 +428,7 @@ class DMRG2:
             acc = 0.0
             for (bra, w, ket), M in env.items():
                 if w == wfin and bra == ket and bra in spec:
-                    s2 = (bra[1] + 1) * np.asarray(spec[bra]) ** 2
+                    s2 = self.sym.qdim(bra) * np.asarray(spec[bra]) ** 2
                     acc += float(np.real(np.sum(np.diag(M)[:len(s2)] * s2)))
             run[i] = acc
         run[L - 1] = E_tot

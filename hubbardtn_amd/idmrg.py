@@ -33,7 +33,7 @@ def unit_cell(P: int, Q: int) -> int:
     return Q if P % 2 == 0 else 2 * Q
 
 
-def _spectrum_distance(a: dict, b: dict, dN: int) -> float:
+def _spectrum_distance(a: dict, b: dict, dN: int, sym=models.SU2U1) -> float:
     """|| S_a - S_b || over sectors, b's labels shifted back by dN, shorter spectra zero padded"""
     keys = set(a) | {(N - dN, j) for (N, j) in b}
     d2 = 0.0
@@ -43,7 +43,7 @@ def _spectrum_distance(a: dict, b: dict, dN: int) -> float:
         n = max(len(x), len(y))
         x = np.pad(x, (0, n - len(x)))
         y = np.pad(y, (0, n - len(y)))
-        d2 += (k[1] + 1) * float(np.sum((x - y) ** 2))
+        d2 += sym.qdim(k) * float(np.sum((x - y) ** 2))
     return float(np.sqrt(d2))
 
 
@@ -66,6 +66,7 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
     truncbelow(cutoff) exactly as in the finite engine."""
     P, Q = int(sim.P), int(sim.Q)
     B = int(sim.bands)
+    sym = models.symmetry_of(sim)
     T = unit_cell(P, Q) * B                  # sites per unit cell
     W = 2 * T
     dNw = (W * P) // Q                       # particles in a window (integer: the cell length is a multiple of Q)
@@ -77,18 +78,18 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
     sites = [big[m0 + i] for i in range(W)]
     key = lambda w: (tuple(w.left), tuple(w.right), tuple(w.entries))
     assert key(big[m0]) == key(big[m0 + T]) == key(big[m0 + W]), "MPO is not periodic with the unit cell"
-    cmpo = _engine.CMpo(ops, sites)
+    cmpo = _engine.CMpo(ops, models.MPO(sites, sym))
     # step 0: the window alone.  Its MPO bonds are the bulk's (full width), so "open ends" are explicit boundary
     # environments: an empty chain to the left (only the implicit identity level is non-zero) and to the right
     bL = {(0, 0): 1}
     bR = {(dNw, 0): 1}
-    Lenv = _zero_env(bL, sites[0].left, "L")
-    Renv = _zero_env(bR, sites[W - 1].right, "R")
+    Lenv = _zero_env(bL, sites[0].left, "L", sym)
+    Renv = _zero_env(bR, sites[W - 1].right, "R", sym)
     E_prev, spec_prev, e_site, delta = None, None, float("nan"), float("inf")
     history = []
     eng = None
     for it in range(maxiter):
-        bonds, tensors = mps.random_window(W, bL, bR, init_dimension, seed=seed + it)
+        bonds, tensors = mps.random_window(W, bL, bR, init_dimension, seed=seed + it, sym=sym)
         eng = _engine.DMRG2(ops, cmpo, bonds, tensors, chi_full=chi_full, cutoff=cutoff, krylovdim=krylovdim,
                             lanczos_tol=lanczos_tol, left_env=Lenv, right_env=Renv)
         boundary = {"bL": dict(bL), "bR": dict(bR), "Lenv": Lenv, "Renv": Renv}
@@ -107,7 +108,7 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
         spec = eng.spectrum(T)
         if E_prev is not None:
             e_site = (E - E_prev) / W
-            delta = _spectrum_distance(spec_prev, spec, dNw // 2)
+            delta = _spectrum_distance(spec_prev, spec, dNw // 2, sym)
         history.append((e_site, delta))
         if verbosity:
             print(f"IDMRG2 step {it + 1}: sites {W * (it + 1)}  E/site = {e_site:.10f}  delta = {delta:.3e}  "
@@ -126,7 +127,7 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
                        bond_dims=eng.bond_dims(), spectrum=spec_prev, history=history, engine=eng, boundary=boundary)
 
 
-def _zero_env(bond: dict, levels, side: str) -> np.ndarray:
+def _zero_env(bond: dict, levels, side: str, sym=models.SU2U1) -> np.ndarray:
     """environment of an EMPTY block beyond an open end, for a full-width MPO bond: every explicit level is zero
     (the identity level -- 'nothing applied yet' on the left, 'complete' on the right -- is implicit).  Size = sum over
     non-identity levels and connected (ket, bra) pairs of n_bra n_ket; for the one-sector boundary bonds used here:"""
@@ -137,6 +138,6 @@ def _zero_env(bond: dict, levels, side: str) -> np.ndarray:
             continue
         for ket, nk in bond.items():
             for bra, nb in bond.items():
-                if bra[0] == ket[0] + dN and abs(ket[1] - k) <= bra[1] <= ket[1] + k and (ket[1] + k + bra[1]) % 2 == 0:
+                if bra[0] == ket[0] + dN and sym.triangle(ket[1], k, bra[1]):
                     size += nb * nk
     return np.zeros(max(size, 1), dtype=np.complex128)

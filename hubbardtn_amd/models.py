@@ -68,6 +68,87 @@ TERM_CHANNELS = {
 }
 
 
+# ---- symmetry descriptors --------------------------------------------------------------------------------------
+class Symmetry:
+    """sector arithmetic + reduced site operators of one symmetry kind (mirrors htn_symmetry of the C ABI).
+    kind 0: fZ2 x SU(2) x U(1) (src:250): label (N, 2S), spins couple; kind 1: fZ2 x U(1) x U(1) (src:247): label
+    (N, 2Sz), both additive (`spin=true` of the reference)."""
+
+    def __init__(self, kind, name, site_mult, site_ops, channels):
+        self.kind, self.name = kind, name
+        self.site_mult, self.site_ops, self.channels = tuple(site_mult), site_ops, channels
+        self.n_site = len(self.site_mult)
+
+    @property
+    def su2(self):
+        return self.kind != 1
+
+    def qdim(self, sec):
+        return sec[1] + 1 if self.su2 else 1
+
+    def triangle(self, a, k, b):
+        if not self.su2:
+            return a + k == b
+        return abs(a - k) <= b <= a + k and (a + k + b) % 2 == 0
+
+    def fuse(self, sec, s):
+        """sectors reachable from `sec` by adding site multiplet s"""
+        N, j = sec
+        Ns, js = self.site_mult[s]
+        if not self.su2:
+            return [(N + Ns, j + js)]
+        return [(N + Ns, jj) for jj in range(abs(j - js), j + js + 1, 2)]
+
+    def split(self, sec, s):
+        """sectors c with c (x) s -> sec"""
+        N, j = sec
+        Ns, js = self.site_mult[s]
+        if N < Ns:
+            return []
+        if not self.su2:
+            return [(N - Ns, j - js)]
+        return [(N - Ns, jj) for jj in range(abs(j - js), j + js + 1, 2)]
+
+
+class MPO(list):
+    """list of MPOSite + the symmetry its labels live in"""
+
+    def __init__(self, sites, sym):
+        super().__init__(sites)
+        self.sym = sym
+
+
+def _mat4(entries):
+    m = np.zeros((4, 4))
+    for (o, i), v in entries.items():
+        m[o, i] = v
+    return m
+
+
+# spinful site states (src:247-248): 0 empty (0, 0), 1 up (1, +1), 2 down (1, -1), 3 double (2, 0); the operator
+# matrices are the Jordan-Wigner 4 x 4 matrices themselves (all Clebsch-Gordan factors are 1), basis order
+# |0>, |up>, |dn>, |up dn> = c+_up c+_dn |0>; name -> (change of 2Sz, dN, matrix[out, in])
+_A_UP = _mat4({(0, 1): 1, (2, 3): 1})            # a_up |up> = |0>, a_up |updn> = |dn>
+_A_DN = _mat4({(0, 2): 1, (1, 3): -1})           # a_dn |dn> = |0>, a_dn |updn> = -|up>
+_F4 = np.diag([1.0, -1.0, -1.0, 1.0])
+SITE_MULT_U1 = ((0, 0), (1, 1), (1, -1), (2, 0))
+SITE_OPS_U1 = {
+    "id": (0, 0, np.eye(4)),
+    "F": (0, 0, _F4),
+    "n": (0, 0, np.diag([0.0, 1.0, 1.0, 2.0])),
+    "docc": (0, 0, np.diag([0.0, 0.0, 0.0, 1.0])),
+    "sz": (0, 0, np.diag([0.0, 0.5, -0.5, 0.0])),                   # Sz(), src:329-339
+    "cdagF_up": (+1, +1, _A_UP.T @ _F4), "c_up": (-1, -1, _A_UP), "Fc_up": (-1, -1, _F4 @ _A_UP), "cdag_up": (+1, +1, _A_UP.T),
+    "cdagF_dn": (-1, +1, _A_DN.T @ _F4), "c_dn": (+1, -1, _A_DN), "Fc_dn": (+1, -1, _F4 @ _A_DN), "cdag_dn": (-1, +1, _A_DN.T),
+}
+# c+_{i s} c_{j s} = (a+_s F)_i F.. (a_s)_j ;  c+_{j s} c_{i s} = (F a_s)_i F.. (a+_s)_j   (i < j): unit factors
+TERM_CHANNELS_U1 = {
+    "hop": (("hop_up+", (+1, +1), "cdagF_up", "F", "c_up", 1.0), ("hop_up-", (-1, -1), "Fc_up", "F", "cdag_up", 1.0),
+            ("hop_dn+", (+1, -1), "cdagF_dn", "F", "c_dn", 1.0), ("hop_dn-", (-1, +1), "Fc_dn", "F", "cdag_dn", 1.0)),
+    "nn": (("nn", (0, 0), "n", "id", "n", 1.0),),
+}
+
+
 class Simulation:
     pass
 
@@ -150,10 +231,11 @@ class MPOSite:
     entries: list     # [(wl, wr, opname, coef)]
 
 
-def _build_mpo(nsites, onsite, pairs):
+def _build_mpo(nsites, onsite, pairs, sym=None):
     """onsite: {site: [(opname, coef)]}; pairs: list of (i, j, kind, coef) with i < j (0-based), kind in
     TERM_CHANNELS.  Finite-state-machine MPO: level 0 = nothing applied ('start'), last = complete ('final'),
     one chain of levels per open two-site term (no compression, like `H += h`, src:439)."""
+    sym = sym or SU2U1
     chan_def = {}
     chans = {b: [] for b in range(nsites + 1)}      # bond b sits to the right of site b-1
     coefs = {}
@@ -162,7 +244,9 @@ def _build_mpo(nsites, onsite, pairs):
             continue
         coefs[(i, j, kind)] = coefs.get((i, j, kind), 0.0) + coef
     for (i, j, kind), coef in coefs.items():
-        for (sub, q, op_open, op_pass, op_close, fac) in TERM_CHANNELS[kind]:
+        if kind not in sym.channels:
+            raise NotImplementedError(f"term kind '{kind}' is not available in the {sym.name} mode (SURVEY 8f.2)")
+        for (sub, q, op_open, op_pass, op_close, fac) in sym.channels[kind]:
             chan_def[(sub, i, j)] = (q, op_open, op_pass, op_close, fac * coef)
             for b in range(i + 1, j + 1):
                 chans[b].append((sub, i, j))
@@ -204,7 +288,7 @@ def _build_mpo(nsites, onsite, pairs):
             if name[2] == s:
                 ent.append((il[name], ir[("final",)], op_close, c))
         sites.append(MPOSite(ql, qr, ent))
-    return sites
+    return MPO(sites, sym)
 
 
 def _exchange(pairs, i, j, J):
@@ -238,15 +322,26 @@ def _assisted_hop(pairs, a, b, U):
         pairs.append((b, a, "dhopL", U))
 
 
+SU2U1 = Symmetry(0, "SU(2)xU(1)", SITE_MULT, SITE_OPS, TERM_CHANNELS)
+U1U1 = Symmetry(1, "U(1)xU(1) (spin=true)", SITE_MULT_U1, SITE_OPS_U1, TERM_CHANNELS_U1)
+
+
+def symmetry_of(sim) -> Symmetry:
+    """`spin=true` selects fZ2 x U(1) x U(1) (src:246-248), the default is fZ2 x SU(2) x U(1) (src:249-251)"""
+    return U1U1 if bool(sim.kwargs.get("spin", False)) else SU2U1
+
+
 def hamiltonian(sim: Simulation, L: int):
-    """Reduced open-chain MPO over L unit cells (L*B sites).  Returns list[MPOSite]."""
+    """Reduced open-chain MPO over L unit cells (L*B sites).  Returns MPO (a list of MPOSite with `.sym`)."""
+    sym = symmetry_of(sim)
     if isinstance(sim, OB_Sim):
         if sim.period != 0:
             raise NotImplementedError("helix (period != 0) is outside the hot-path scope (SURVEY 8f)")
-        for key in ("JMs",):
-            if sim.kwargs.get(key, (0.0, 0.0))[1] != 0.0 and sim.kwargs.get("spin", False):
-                raise NotImplementedError("staggered field needs the spinful U(1)xU(1) mode (SURVEY 8f.2)")
         onsite = {s: [("docc", sim.u[0]), ("n", -sim.mu)] for s in range(L)}          # src:424
+        J_inter, Ms = (float(x) for x in sim.kwargs.get("JMs", (0.0, 0.0)))
+        if Ms != 0.0 and sym is U1U1:                                                 # staggered field, src:459-463
+            for s in range(L):
+                onsite[s].append(("sz", J_inter * Ms * (-1.0) ** (s + 1)))
         pairs = []
         for r, tr in enumerate(sim.t, start=1):                                       # src:437-440
             for i in range(L - r):
@@ -261,7 +356,7 @@ def hamiltonian(sim: Simulation, L: int):
             for i in range(L - r):
                 _assisted_hop(pairs, i, i + r, float(Ur))
                 _assisted_hop(pairs, i + r, i, float(Ur))
-        return _build_mpo(L, onsite, pairs)
+        return _build_mpo(L, onsite, pairs, sym)
     if isinstance(sim, MB_Sim):
         B = sim.bands
         t, u, Jm = sim.t, sim.u, sim.J
@@ -323,5 +418,5 @@ def hamiltonian(sim: Simulation, L: int):
                             i, j = site(bi, cell), site(bf, cell + r)
                             _assisted_hop(pairs, i, j, 0.5 * (M[bi, bf, 0] + M[bi, bf, 1]))      # density on j
                             _assisted_hop(pairs, j, i, 0.5 * (M[bi, bf, 2] + M[bi, bf, 3]))      # density on i
-        return _build_mpo(n, onsite, pairs)
+        return _build_mpo(n, onsite, pairs, sym)
     raise TypeError(f"unsupported simulation type {type(sim)}")

@@ -174,3 +174,32 @@ def test_runs_are_bit_reproducible(hip_ops):
     bnd = eng.bonds
     tl = ThetaLayout.build(bnd[7], bnd[9])
     assert max(min(tl.mats[c][1], tl.mats[c][2]) for c in tl.mids) > 96      # a block beyond one CU's LDS window
+
+
+def test_spinful_u1u1_mode_matches_exact_diagonalisation(hip_ops):
+    """`spin=true` (fZ2 x U(1) x U(1), src:246-248, 260-280): abelian sectors, four site states, unit recoupling
+    coefficients through the same kernels: energy and exact Schmidt spectrum per (N, 2Sz) sector vs ED; agreement with
+    the SU(2) x U(1) mode under the reference's truncation truncbelow"""
+    from oracle import ed
+    L = 8
+    H = models.hamiltonian(models.OB_Sim([1.0], [4.0], 0.0, 1, 1, 2.0, 8, spin=True), L)
+    bonds, tens = mps.random_mps(L, (L, 0), 40, seed=3, sym=H.sym)
+    eng = engine.DMRG2(hip_ops, H, bonds, tens, chi_full=None)
+    for _ in range(3):
+        E = eng.sweep()
+    sec = ed.SectorED(L, 4, 4, [1.0], [4.0])
+    E0, psi = sec.ground_state()
+    assert abs(E - E0) < 1e-10 and eng.bond_dims()[4] == 256
+    got = eng.spectrum(4)
+    for c, v in sec.schmidt_by_sector(psi, 4).items():
+        v = v[v > 1e-12]
+        if len(v):
+            assert np.abs(got[c][:len(v)] - v).max() < 1e-9, c
+    Es = {}
+    for spin in (False, True):
+        Hs = models.hamiltonian(models.OB_Sim([1.0, 0.2], [5.0, 0.4], 0.0, 1, 1, 2.0, 8, spin=spin), 10)
+        b, t_ = mps.random_mps(10, (10, 0), 60 if spin else 30, seed=5, sym=Hs.sym)
+        e = engine.DMRG2(hip_ops, Hs, b, t_, chi_full=None, cutoff=3e-3, lanczos_tol=1e-12)
+        for _ in range(4):
+            Es[spin] = e.sweep()
+    assert abs(Es[True] - Es[False]) < 1e-9 * abs(Es[False])

@@ -45,3 +45,25 @@ def test_two_band_reference_constant():
     E = float(np.sum(np.real(api.expectation_value(d["groundstate"], H)))) / len(H)
     assert len(H) == 4
     assert abs(E - rec["E_per_site"]) < rec["atol"]
+
+
+def test_spinful_reference_constants():
+    """test/Spin.jl:14-47: the fZ2 x U(1) x U(1) mode (`spin=true`): one band U = 8 -> -0.32637, two decoupled bands
+    U = 3 -> -0.63093 (atol 1e-1), through the reference's call sequence; plus the density consistency check of
+    test/Spin.jl:76-85"""
+    model1 = api.OB_Sim([1.0], [8.0], 0.0, 1, 1, 2.0, spin=True)
+    d1 = api.produce_groundstate(model1, tol=1e-4, maxiter=40)
+    H1 = d1["ham"]
+    E1 = float(np.sum(np.real(api.expectation_value(d1["groundstate"], H1)))) / len(H1)
+    assert abs(E1 - (-0.32637)) < 1e-1 and abs(E1 - (-0.32637)) < 2e-3
+    t = np.array([[0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    u = np.array([[3.0, 0.0, 0.0, 0.0], [0.0, 3.0, 0.0, 0.0]])
+    model2 = api.MB_Sim(t, u, np.zeros((2, 2)), 1, 1, 2.0, 20, code="Spin", spin=True)
+    d2 = api.produce_groundstate(model2, tol=1e-4, maxiter=40)
+    H2 = d2["ham"]
+    E2 = float(np.sum(np.real(api.expectation_value(d2["groundstate"], H2)))) / len(H2)
+    assert len(H2) == 4 and abs(E2 - (-0.63093)) < 1e-1 and abs(E2 - (-0.63093)) < 5e-3
+    for d in (d1, d2):
+        n = api.density_state(d["groundstate"])
+        up, dn = api.density_spin(d["groundstate"])
+        assert abs(n.sum() - (up + dn).sum()) < 1e-8 and abs(n.sum() / len(d["ham"]) - 1.0) < 5e-3

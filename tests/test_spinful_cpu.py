@@ -1,0 +1,157 @@
+"""The spinful fZ2 x U(1) x U(1) mode (`spin=true`: SymSpace / Hopping / Sz of src/HubbardFunctions.jl:246-248, 260-280,
+329-339; staggered field src:459-463; density_spin / calc_ms src:1412-1473) on the C++ engine with the CPU backend:
+dense checks of the builder, exact diagonalisation (energy and the exact Schmidt spectrum per (N, 2Sz) sector), agreement
+with the SU(2) x U(1) mode, and the reference's own spinful constant (test/Spin.jl:14, 42) through IDMRG2."""
+import numpy as np
+import pytest
+
+from cpu_ops import CpuOps
+from hubbardtn_amd import api, engine, models, mps
+from oracle import ed
+
+
+@pytest.fixture(scope="module")
+def cpu_ops():
+    return CpuOps()
+
+
+def _dense_from_abelian_mpo(H):
+    """contract an abelian (all CG factors 1) MPO to the 4^L x 4^L matrix, site 0 most significant"""
+    ops = H.sym.site_ops
+    cur = None                                     # [level][row, col]
+    for W in H:
+        nxt = {}
+        for (wl, wr, name, coef) in W.entries:
+            m = coef * ops[name][2]
+            if cur is None:
+                term = m
+            elif wl in cur:
+                term = np.kron(cur[wl], m)
+            else:
+                continue
+            nxt[wr] = nxt.get(wr, 0) + term
+        cur = nxt
+    assert list(cur) == [0]
+    return cur[0]
+
+
+def test_spinful_mpo_equals_dense_hamiltonian_including_the_staggered_field():
+    from oracle import su2
+    L, t, u, mu = 4, [1.0, 0.3], [4.0, 0.5], 0.2
+    H = models.hamiltonian(models.OB_Sim(t, u, mu, 1, 1, 2.0, 8, spin=True, JMs=(0.7, 0.4)), L)
+    assert H.sym is models.U1U1 and H.sym.site_mult == ((0, 0), (1, 1), (1, -1), (2, 0))
+    M = _dense_from_abelian_mpo(H)
+    ref = ed.dense_hamiltonian(L, t, u, mu)
+    lm = su2.local_matrices()
+    sz = 0.5 * (lm["a_up"].T @ lm["a_up"] - lm["a_dn"].T @ lm["a_dn"])
+    for i in range(L):                             # J_inter Ms sz_i (-1)^i, i = 1 .. L (src:459-463)
+        op = np.eye(1)
+        for s in range(L):
+            op = np.kron(op, sz if s == i else np.eye(4))
+        ref = ref + 0.7 * 0.4 * (-1.0) ** (i + 1) * op
+    assert np.abs(M - ref).max() < 1e-13 and np.abs(M - M.T).max() < 1e-14
+    # every operator's charges are what the level labels of its channels assume
+    for name, (k, dN, m) in H.sym.site_ops.items():
+        for o in range(4):
+            for i in range(4):
+                if m[o, i] != 0.0:
+                    No, jo = H.sym.site_mult[o]
+                    Ni, ji = H.sym.site_mult[i]
+                    assert (No - Ni, jo - ji) == (dN, k), name
+
+
+def test_spinful_engine_matches_exact_diagonalisation_and_its_schmidt_spectrum(cpu_ops):
+    L = 8
+    sim = models.OB_Sim([1.0], [4.0], 0.0, 1, 1, 2.0, 8, spin=True)
+    H = models.hamiltonian(sim, L)
+    bonds, tens = mps.random_mps(L, (L, 0), 40, seed=3, sym=H.sym)
+    eng = engine.DMRG2(cpu_ops, H, bonds, tens, chi_full=None)
+    for _ in range(3):
+        E = eng.sweep()
+    sec = ed.SectorED(L, 4, 4, [1.0], [4.0])
+    E0, psi = sec.ground_state()
+    assert abs(E - E0) < 1e-10 and eng.bond_dims()[4] == 256
+    exact = sec.schmidt_by_sector(psi, 4)          # (N_left, N_up - N_dn) -> singular values
+    got = eng.spectrum(4)
+    for c, v in exact.items():
+        v = v[v > 1e-12]
+        if len(v) == 0:
+            continue
+        g = got[c][:len(v)]
+        assert np.abs(g - v).max() < 1e-9, c
+    assert abs(sum(float(np.sum(v ** 2)) for v in got.values()) - 1.0) < 1e-12      # unit weights: qdim = 1
+    n = eng.site_occupations()[0]
+    up, dn = eng.spin_occupations()
+    assert np.abs(up - dn).max() < 1e-8 and np.abs(up + dn - n).max() < 1e-12 and abs(n.sum() - L) < 1e-10
+
+
+def test_spinful_and_su2_modes_agree_under_the_reference_truncation(cpu_ops):
+    """truncbelow(eta) keeps the same physical Schmidt values in both representations (a spin-S multiplet is one
+    reduced value there, 2S+1 equal values here): energies of the truncated sweeps coincide"""
+    L, t, u = 10, [1.0, 0.2], [5.0, 0.4]
+    Es = {}
+    for spin in (False, True):
+        H = models.hamiltonian(models.OB_Sim(t, u, 0.0, 1, 1, 2.0, 8, spin=spin), L)
+        bonds, tens = mps.random_mps(L, (L, 0), 60 if spin else 30, seed=5, sym=H.sym)
+        eng = engine.DMRG2(cpu_ops, H, bonds, tens, chi_full=None, cutoff=3e-3, lanczos_tol=1e-12)
+        for _ in range(4):
+            E = eng.sweep()
+        Es[spin] = (E, eng.bond_dims())
+    assert abs(Es[True][0] - Es[False][0]) < 1e-9 * abs(Es[False][0])
+    assert Es[True][1] == Es[False][1]             # TensorKit dims: sum (2S+1) n  ==  sum n
+
+
+def test_density_spin_with_a_staggered_field_matches_dense_diagonalisation(cpu_ops):
+    L = 6
+    sim = api.OB_Sim([1.0], [3.0], 0.0, 1, 1, 2.0, 8, spin=True, JMs=(1.0, 0.3), L=L)
+    H = api.hamiltonian(sim)
+    psi = api.initialize_mps(H, 1, 30, True, ops=cpu_ops)
+    psi, _, _ = api.find_groundstate(psi, H, api.DMRG2(trscheme=None, tol=1e-12, maxiter=6, eigsolve_tol=1e-13))
+    up, dn = api.density_spin(psi)
+    # dense reference in the N = L, Sz = 0 sector
+    M = _dense_from_abelian_mpo(H)
+    lm_n = np.diag([0.0, 1.0, 1.0, 2.0])
+    lm_sz = np.diag([0.0, 0.5, -0.5, 0.0])
+
+    def total(op):
+        out = np.zeros(4 ** L)
+        for i in range(L):
+            d = np.ones(1)
+            for s in range(L):
+                d = np.kron(d, np.diag(op) if s == i else np.ones(4))
+            out = out + d
+        return out
+    keep = np.nonzero((np.abs(total(lm_n) - L) < 1e-9) & (np.abs(total(lm_sz)) < 1e-9))[0]
+    w, v = np.linalg.eigh(M[np.ix_(keep, keep)])
+    assert abs(psi.engine.energy - w[0]) < 1e-10
+    prob = np.zeros(4 ** L)
+    prob[keep] = np.abs(v[:, 0]) ** 2
+    for i in range(L):
+        d = np.ones(1)
+        dd = np.ones(1)
+        for s in range(L):
+            d = np.kron(d, np.array([0.0, 1.0, 0.0, 1.0]) if s == i else np.ones(4))
+            dd = np.kron(dd, np.array([0.0, 0.0, 1.0, 1.0]) if s == i else np.ones(4))
+        assert abs(up[i] - prob @ d) < 1e-8 and abs(dn[i] - prob @ dd) < 1e-8
+    assert api.calc_ms(psi) > 1e-3                 # the field polarises the first site
+    with pytest.raises(ValueError, match="spin independent"):
+        sim0 = api.OB_Sim([1.0], [3.0], 0.0, 1, 1, 2.0, 8, L=4)
+        H0 = api.hamiltonian(sim0)
+        p0 = api.initialize_mps(H0, 1, 8, ops=cpu_ops)
+        p0, _, _ = api.find_groundstate(p0, H0, api.DMRG2(trscheme=None, tol=1e-8, maxiter=2))
+        api.density_spin(p0)
+
+
+def test_spinful_reference_constant_through_idmrg2(cpu_ops):
+    """test/Spin.jl:14, 42-47: OB_Sim([1.0], [8.0], 0.0, 1, 1, 2.0; spin=true) -> E/site = -0.32637 (atol 1e-1)"""
+    sim = api.OB_Sim([1.0], [8.0], 0.0, 1, 1, 2.0, 8, spin=True)
+    H = api.hamiltonian(sim)
+    psi = api.initialize_mps(H, sim.P, sim.bond_dim, True, ops=cpu_ops)
+    psi, envs, delta = api.find_groundstate(psi, H, api.IDMRG2(trscheme=api.truncbelow(10.0 ** -sim.svalue), tol=5e-3, maxiter=12,
+                                                              eigsolve_tol=1e-9, sweeps_per_step=3))
+    E = float(np.sum(np.real(api.expectation_value(psi, H)))) / len(H)
+    assert len(H) == 2 and abs(E - (-0.32637)) < 1e-1         # the reference's own tolerance
+    assert abs(E - (-0.32637)) < 2e-3 and abs(E - (-0.3275305344)) < 2e-3      # and the Lieb-Wu value
+    up, dn = api.density_spin(psi)
+    n = api.density_state(psi)
+    assert abs(n.sum() / 2 - (up + dn).sum() / len(H)) < 1e-8                  # test/Spin.jl:76-79
