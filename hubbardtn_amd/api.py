@@ -27,7 +27,7 @@ import numpy as np
 from . import engine as _engine
 from . import idmrg as _idmrg
 from . import models, mps
-from .models import MB_Sim, OB_Sim, Simulation
+from .models import MB_Sim, MBC_Sim, OB_Sim, OBC_Sim, OBC_Sim2, Simulation
 
 
 # ---- truncation schemes (TensorKit names; App. A.6) --------------------------------------------
@@ -72,7 +72,7 @@ class InfiniteHamiltonian:
     simul: Simulation
 
     def __len__(self):
-        return _idmrg.unit_cell(self.simul.P, self.simul.Q) * self.simul.bands
+        return _idmrg.cell_sites(self.simul)
 
 
 @dataclass
@@ -124,13 +124,23 @@ def hamiltonian(simul: Simulation, L: int | None = None):
     return models.hamiltonian(simul, int(L))
 
 
-def initialize_mps(H, P: int, max_dimension: int, spin: bool = False, Q: int = 1, seed: int = 1234, ops=None):
+def initialize_mps(H, P: int, max_dimension: int | None = None, spin: bool = False, Q: int = 1, seed: int = 1234, ops=None):
     """random right-canonical start with per-sector cap `max_dimension` (src:917-959); the symmetry mode (SU(2) x U(1),
-    or U(1) x U(1) for `spin=true`) is the Hamiltonian's"""
+    or U(1) x U(1) for `spin=true`) is the Hamiltonian's.  The chemical-potential models use the reference's two-argument
+    form `initialize_mps(operator, max_dimension)` (src:961-991)."""
+    if isinstance(H, InfiniteHamiltonian) and models.symmetry_of(H.simul).kind == 2 or getattr(H, "sym", None) is models.SU2P:
+        # (parity 0, S = 0) total sector on a finite chain: an even number of electrons in a singlet
+        max_dimension = P if max_dimension is None else max_dimension
+        if isinstance(H, InfiniteHamiltonian):
+            return InfiniteMPS(int(max_dimension), seed, ops)
+        bonds, tensors = mps.random_mps(len(H), (0, 0), int(max_dimension), seed=seed, sym=models.SU2P)
+        return FiniteMPS(_engine.DMRG2(ops or _ops(), H, bonds, tensors), len(H))
     if isinstance(H, InfiniteHamiltonian):
         if bool(spin) != (not models.symmetry_of(H.simul).su2):
             raise ValueError("initialize_mps: `spin` does not match the Hamiltonian's symmetry mode")
         return InfiniteMPS(int(max_dimension), seed, ops)
+    if max_dimension is None:
+        raise TypeError("initialize_mps(H, P, max_dimension, spin, Q): max_dimension is required for the fixed-filling models")
     nsites = len(H)
     sym = getattr(H, "sym", models.SU2U1)
     if bool(spin) != (not sym.su2):
@@ -259,7 +269,7 @@ def _load_result(simul, entry, L=None, ops=None, **kw):
     ops = ops or _ops()
     if meta["kind"] == "infinite":
         T = meta["unit_cell"]
-        big = models.hamiltonian(simul, 8 * _idmrg.unit_cell(simul.P, simul.Q))
+        big = models.hamiltonian(simul, 8 * max(meta["unit_cell"] // simul.bands, 1))
         window = [big[3 * T + i] for i in range(2 * T)]
         eng = _engine.DMRG2(ops, window, bonds, tensors, chi_full=meta["chi_full"], cutoff=meta["cutoff"],
                             left_env=np.load(os.path.join(entry, "left_env.npy")),

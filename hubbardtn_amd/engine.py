@@ -374,7 +374,7 @@ class DMRG2:
     def site_occupations(self):
         """-> (n, d): <n_i> and the double occupancy <n_up n_dn>_i of every site (density_state, src:1495-1523)"""
         P = self.site_probabilities()
-        Ns = np.array([m[0] for m in self.sym.site_mult], dtype=float)          # electrons of every site multiplet
+        Ns = np.array(self.sym.site_electrons, dtype=float)                     # electrons of every site multiplet
         return P @ Ns, P[:, -1].copy()                                            # (the last multiplet is the doubly occupied one)
 
     def spin_occupations(self):

@@ -33,6 +33,16 @@ def unit_cell(P: int, Q: int) -> int:
     return Q if P % 2 == 0 else 2 * Q
 
 
+def cell_sites(sim) -> int:
+    """sites per unit cell of the infinite chain: T B with T = Q or 2Q for the fixed-filling models (src:408-412,
+    832-836); the chemical-potential models have T = 1 (src:417, 841) -- a one-band cell of ONE site is doubled here,
+    because the growing window needs a bond inside each half"""
+    B = int(sim.bands)
+    if models.symmetry_of(sim).kind == 2:
+        return max(B, 2)
+    return unit_cell(int(sim.P), int(sim.Q)) * B
+
+
 def _spectrum_distance(a: dict, b: dict, dN: int, sym=models.SU2U1) -> float:
     """|| S_a - S_b || over sectors, b's labels shifted back by dN, shorter spectra zero padded"""
     keys = set(a) | {(N - dN, j) for (N, j) in b}
@@ -67,12 +77,12 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
     P, Q = int(sim.P), int(sim.Q)
     B = int(sim.bands)
     sym = models.symmetry_of(sim)
-    T = unit_cell(P, Q) * B                  # sites per unit cell
+    T = cell_sites(sim)                      # sites per unit cell
     W = 2 * T
     dNw = (W * P) // Q                       # particles in a window (integer: the cell length is a multiple of Q)
     assert (W * P) % Q == 0
     # translation-invariant MPO sites from the bulk of a long open chain
-    ncells = 8 * unit_cell(P, Q)
+    ncells = 8 * max(T // B, 1)
     big = models.hamiltonian(sim, ncells)
     m0 = 3 * T
     sites = [big[m0 + i] for i in range(W)]
@@ -82,7 +92,7 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
     # step 0: the window alone.  Its MPO bonds are the bulk's (full width), so "open ends" are explicit boundary
     # environments: an empty chain to the left (only the implicit identity level is non-zero) and to the right
     bL = {(0, 0): 1}
-    bR = {(dNw, 0): 1}
+    bR = {(sym.wrap(dNw), 0): 1}
     Lenv = _zero_env(bL, sites[0].left, "L", sym)
     Renv = _zero_env(bR, sites[W - 1].right, "R", sym)
     E_prev, spec_prev, e_site, delta = None, None, float("nan"), float("inf")
@@ -108,7 +118,7 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
         spec = eng.spectrum(T)
         if E_prev is not None:
             e_site = (E - E_prev) / W
-            delta = _spectrum_distance(spec_prev, spec, dNw // 2, sym)
+            delta = _spectrum_distance(spec_prev, spec, 0 if sym.kind == 2 else dNw // 2, sym)
         history.append((e_site, delta))
         if verbosity:
             print(f"IDMRG2 step {it + 1}: sites {W * (it + 1)}  E/site = {e_site:.10f}  delta = {delta:.3e}  "
@@ -122,7 +132,7 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
         # right one from the leftward pass, and truncdim may have kept different counts in between)
         Lenv, Renv = eng.env_data("L", T), eng.env_data("R", T)
         bL = dict(eng.env_bond("L", T).dims)
-        bR = {(N + dNw, j): n for (N, j), n in eng.env_bond("R", T).dims.items()}
+        bR = {(sym.wrap(N + dNw), j): n for (N, j), n in eng.env_bond("R", T).dims.items()}
     return IDMRGResult(energy_per_site=e_site, delta=delta, iterations=len(history), unit_cell=T,
                        bond_dims=eng.bond_dims(), spectrum=spec_prev, history=history, engine=eng, boundary=boundary)
 
@@ -138,6 +148,6 @@ def _zero_env(bond: dict, levels, side: str, sym=models.SU2U1) -> np.ndarray:
             continue
         for ket, nk in bond.items():
             for bra, nb in bond.items():
-                if bra[0] == ket[0] + dN and sym.triangle(ket[1], k, bra[1]):
+                if sym.connects(ket, dN, k, bra):
                     size += nb * nk
     return np.zeros(max(size, 1), dtype=np.complex128)

@@ -72,12 +72,16 @@ TERM_CHANNELS = {
 class Symmetry:
     """sector arithmetic + reduced site operators of one symmetry kind (mirrors htn_symmetry of the C ABI).
     kind 0: fZ2 x SU(2) x U(1) (src:250): label (N, 2S), spins couple; kind 1: fZ2 x U(1) x U(1) (src:247): label
-    (N, 2Sz), both additive (`spin=true` of the reference)."""
+    (N, 2Sz), both additive (`spin=true` of the reference); kind 2: fZ2 x SU(2) (src:341-346, the chemical-potential
+    models): label (parity, 2S) -- N is counted modulo 2, the empty and the doubly occupied site state share the
+    label (0, 0) (the reference's two-fold degenerate even sector) and stay distinct site multiplets here."""
 
-    def __init__(self, kind, name, site_mult, site_ops, channels):
+    def __init__(self, kind, name, site_mult, site_ops, channels, site_electrons=None):
         self.kind, self.name = kind, name
         self.site_mult, self.site_ops, self.channels = tuple(site_mult), site_ops, channels
         self.n_site = len(self.site_mult)
+        # electrons carried by every site multiplet (the label N only where N is a particle number)
+        self.site_electrons = tuple(site_electrons) if site_electrons is not None else tuple(m[0] for m in self.site_mult)
 
     @property
     def su2(self):
@@ -86,10 +90,17 @@ class Symmetry:
     def qdim(self, sec):
         return sec[1] + 1 if self.su2 else 1
 
+    def wrap(self, N):
+        return N % 2 if self.kind == 2 else N
+
     def triangle(self, a, k, b):
         if not self.su2:
             return a + k == b
         return abs(a - k) <= b <= a + k and (a + k + b) % 2 == 0
+
+    def connects(self, ket, dN, k, bra):
+        """may an MPO level of charge (dN, k) take sector `ket` to sector `bra`"""
+        return bra[0] == self.wrap(ket[0] + dN) and self.triangle(ket[1], k, bra[1])
 
     def fuse(self, sec, s):
         """sectors reachable from `sec` by adding site multiplet s"""
@@ -97,17 +108,17 @@ class Symmetry:
         Ns, js = self.site_mult[s]
         if not self.su2:
             return [(N + Ns, j + js)]
-        return [(N + Ns, jj) for jj in range(abs(j - js), j + js + 1, 2)]
+        return [(self.wrap(N + Ns), jj) for jj in range(abs(j - js), j + js + 1, 2)]
 
     def split(self, sec, s):
         """sectors c with c (x) s -> sec"""
         N, j = sec
         Ns, js = self.site_mult[s]
-        if N < Ns:
+        if self.kind != 2 and N < Ns:
             return []
         if not self.su2:
             return [(N - Ns, j - js)]
-        return [(N - Ns, jj) for jj in range(abs(j - js), j + js + 1, 2)]
+        return [(self.wrap(N - Ns), jj) for jj in range(abs(j - js), j + js + 1, 2)]
 
 
 class MPO(list):
@@ -221,6 +232,40 @@ class MB_Sim(Simulation):
         return self.t.shape[0]
 
 
+class OBC_Sim2(OB_Sim):
+    """One-band Hubbard model with the particle number set by a chemical potential (src:176-192, the struct
+    compute_groundstate iterates on; `OBC_Sim(..., mu=true)` is the same thing): fZ2 x SU(2) sectors, no U(1).
+    OBC_Sim2(t, u, mu, svalue=2.0, bond_dim=50, period=0; kwargs...).  The filling-search variant `OBC_Sim(...; mu=false)`
+    (mu bisection, src:1032-1126) is an outer loop around this and out of the hot-path scope."""
+
+    def __init__(self, t, u, mu, svalue=2.0, bond_dim=50, period=0, **kwargs):
+        if kwargs.get("spin", False):
+            raise ValueError("Spin not implemented.")                       # src:162-164
+        super().__init__(t, u, float(mu), 1, 1, svalue, bond_dim, period, **kwargs)
+
+
+def OBC_Sim(t, u, muf, svalue=2.0, bond_dim=50, period=0, mu=True, **kwargs):
+    """src:154-174: with mu=true the chemical potential is imposed (-> OBC_Sim2); mu=false asks for the filling search"""
+    if not mu:
+        raise NotImplementedError("OBC_Sim(...; mu=false): the chemical-potential bisection (src:1032-1126) is an outer "
+                                  "loop around compute_groundstate, outside the hot-path scope (SURVEY section 2 row 9)")
+    return OBC_Sim2(t, u, muf, svalue, bond_dim, period, **kwargs)
+
+
+class MBC_Sim(MB_Sim):
+    """Multi-band model with the filling set by the diagonal of the on-site hopping matrix (src:194-238): fZ2 x SU(2)
+    sectors.  MBC_Sim(t, u, J, [U13], svalue=2.0, bond_dim=50; kwargs...)"""
+
+    def __init__(self, t, u, J, *args, **kwargs):
+        if kwargs.get("spin", False):
+            raise ValueError("Spin not implemented.")                       # src:218-221
+        args = list(args)
+        extra = [args.pop(0)] if args and isinstance(args[0], np.ndarray) else []
+        defaults = [2.0, 50]
+        vals = args + defaults[len(args):]
+        super().__init__(t, u, J, *extra, 1, 1, vals[0], vals[1], **kwargs)
+
+
 # ----------------------------------------------------------------------------------------------
 # generic finite-chain MPO from a list of terms
 # ----------------------------------------------------------------------------------------------
@@ -324,10 +369,17 @@ def _assisted_hop(pairs, a, b, U):
 
 SU2U1 = Symmetry(0, "SU(2)xU(1)", SITE_MULT, SITE_OPS, TERM_CHANNELS)
 U1U1 = Symmetry(1, "U(1)xU(1) (spin=true)", SITE_MULT_U1, SITE_OPS_U1, TERM_CHANNELS_U1)
+# chemical-potential models: same reduced operators (1, sqrt 2 as src:348-382), labels (parity, 2S); the level labels of
+# the channels keep dN = +-1, +-2 and are wrapped modulo 2 by the sector arithmetic
+SU2P = Symmetry(2, "SU(2) (no U(1): chemical potential)", ((0, 0), (1, 1), (0, 0)), SITE_OPS, TERM_CHANNELS,
+                site_electrons=(0, 1, 2))
 
 
 def symmetry_of(sim) -> Symmetry:
-    """`spin=true` selects fZ2 x U(1) x U(1) (src:246-248), the default is fZ2 x SU(2) x U(1) (src:249-251)"""
+    """`spin=true` selects fZ2 x U(1) x U(1) (src:246-248), the chemical-potential models fZ2 x SU(2) (src:341-346), the
+    default is fZ2 x SU(2) x U(1) (src:249-251)"""
+    if isinstance(sim, (OBC_Sim2, MBC_Sim)):
+        return SU2P
     return U1U1 if bool(sim.kwargs.get("spin", False)) else SU2U1
 
 

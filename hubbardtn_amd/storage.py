@@ -20,7 +20,7 @@ import os
 
 import numpy as np
 
-from .models import MB_Sim, OB_Sim
+from .models import MB_Sim, MBC_Sim, OB_Sim, OBC_Sim2
 
 
 def datadir(*parts):
@@ -47,6 +47,8 @@ def savename(simul) -> str:
                   "μ": simul.mu}
     else:
         fields = {"P": simul.P, "Q": simul.Q, "bond_dim": simul.bond_dim, "svalue": simul.svalue}
+    if isinstance(simul, (OBC_Sim2, MBC_Sim)):             # the chemical-potential structs have no P, Q fields (src:154-238)
+        fields.pop("P"), fields.pop("Q")
     return "_".join(f"{k}={_fmt(v)}" for k, v in sorted(fields.items()))
 
 
@@ -59,13 +61,13 @@ def cache_name(simul, what="groundstate"):
     spin = "spin_" if simul.kwargs.get("spin", False) else "nospin_"
     if isinstance(simul, MB_Sim):
         prefix = f"{what}_{spin}{simul.kwargs.get('code', '')}"
-        sub = "MB"
+        sub = "MBC" if isinstance(simul, MBC_Sim) else "MB"
     else:
         U13 = simul.kwargs.get("U13", [0.0])
         JMs = simul.kwargs.get("JMs", (0.0, 0.0))
         prefix = (f"{what}_{spin}t{_jl_vec(simul.t)}_u{_jl_vec(simul.u)}_J{_jl_vec(simul.J)}_U13{_jl_vec(U13)}"
                   f"_JMs{float(JMs[0])!r}_{float(JMs[1])!r}")
-        sub = "OB"
+        sub = "OBC" if isinstance(simul, OBC_Sim2) else "OB"
     L = simul.kwargs.get("L")
     tail = savename(simul) + (f"_L={int(L)}" if L else "")           # finite chains (not in the reference) get their length
     return sub, f"{prefix}_{tail}"

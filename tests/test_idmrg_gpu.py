@@ -67,3 +67,23 @@ def test_spinful_reference_constants():
         n = api.density_state(d["groundstate"])
         up, dn = api.density_spin(d["groundstate"])
         assert abs(n.sum() - (up + dn).sum()) < 1e-8 and abs(n.sum() / len(d["ham"]) - 1.0) < 5e-3
+
+
+def test_chemical_potential_models_on_the_gpu():
+    """fZ2 x SU(2) sectors without U(1) (OBC_Sim2 / MBC_Sim, src:176-238, 341-382): one band at mu = U/2 reproduces the
+    fixed-filling energy density (and sits within 1e-2 of test/OBC.jl:20's VUMPS-path constant); the two-band model of
+    test/MBC.jl:22-59 meets its constant at the reference's tolerance"""
+    sim = api.OBC_Sim2([1.0], [1.0], 0.5, 2.0)
+    d = api.produce_groundstate(sim, tol=1e-4, maxiter=40)
+    H, psi = d["ham"], d["groundstate"]
+    n = api.density_state(psi)
+    E0 = float(np.sum(api.expectation_value(psi, H))) / len(H) + 0.5 * float(n.mean())
+    assert np.abs(n - 1.0).max() < 1e-5
+    assert abs(E0 - (-1.037173)) < 3e-4 and abs(E0 - (-1.03541433)) < 1e-2
+    t = np.array([[0.5, 0.0, 1.0, 0.0], [0.0, 0.5, 0.0, 1.0]])
+    u = np.array([[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]])
+    simb = api.MBC_Sim(t, u, np.zeros((2, 2)), 2.0, 20, code="MBC")
+    db = api.produce_groundstate(simb, tol=1e-4, maxiter=40)
+    nb = api.density_state(db["groundstate"])
+    Eb = (float(np.sum(api.expectation_value(db["groundstate"], db["ham"]))) + 0.5 * float(nb.sum())) / len(db["ham"])
+    assert abs(Eb - (-1.01631556)) < 1e-1 and Eb > -1.0404
