@@ -276,25 +276,32 @@ class MPOSite:
     entries: list     # [(wl, wr, opname, coef)]
 
 
-def _build_mpo(nsites, onsite, pairs, sym=None):
-    """onsite: {site: [(opname, coef)]}; pairs: list of (i, j, kind, coef) with i < j (0-based), kind in
-    TERM_CHANNELS.  Finite-state-machine MPO: level 0 = nothing applied ('start'), last = complete ('final'),
-    one chain of levels per open two-site term (no compression, like `H += h`, src:439)."""
+def _build_mpo(nsites, onsite, pairs, sym=None, merge=True):
+    """onsite: {site: [(opname, coef)]}; pairs: list of (i, j, kind, coef) with i < j (0-based), kind in the symmetry's
+    term channels.  Finite-state-machine MPO: level 0 = nothing applied ('start'), last = complete ('final'), in
+    between one level per OPEN channel.  merge=True (default): all terms of one channel type that open on the same site
+    share ONE level, which lives until their farthest closing site and closes with each term's own coefficient --
+    sum_j t_ij c+_i c_j needs one "c+_i emitted" level, not one per j.  The Hamiltonian is the same operator; the MPO
+    bond is narrower (range-r hopping: r instead of r (r + 1) / 2 levels per channel type), and the H_eff apply costs
+    proportionally less.  merge=False reproduces the reference's uncompressed sum of per-term MPOs (`H += h`, src:439)."""
     sym = sym or SU2U1
-    chan_def = {}
-    chans = {b: [] for b in range(nsites + 1)}      # bond b sits to the right of site b-1
     coefs = {}
     for (i, j, kind, coef) in pairs:
         if coef == 0.0:
             continue
         coefs[(i, j, kind)] = coefs.get((i, j, kind), 0.0) + coef
+    chan_def = {}                                   # channel -> (q, op_open, op_pass, op_close, {closing site: coefficient})
     for (i, j, kind), coef in coefs.items():
         if kind not in sym.channels:
             raise NotImplementedError(f"term kind '{kind}' is not available in the {sym.name} mode (SURVEY 8f.2)")
         for (sub, q, op_open, op_pass, op_close, fac) in sym.channels[kind]:
-            chan_def[(sub, i, j)] = (q, op_open, op_pass, op_close, fac * coef)
-            for b in range(i + 1, j + 1):
-                chans[b].append((sub, i, j))
+            name = (sub, i) if merge else (sub, i, j)
+            d = chan_def.setdefault(name, (q, op_open, op_pass, op_close, {}))
+            d[4][j] = d[4].get(j, 0.0) + fac * coef
+    chans = {b: [] for b in range(nsites + 1)}      # bond b sits to the right of site b-1
+    for name, d in chan_def.items():
+        for b in range(name[1] + 1, max(d[4]) + 1):
+            chans[b].append(name)
 
     def levels(b):
         if b == 0:
@@ -321,7 +328,7 @@ def _build_mpo(nsites, onsite, pairs, sym=None):
         for name in nr:
             if name[0] in ("start", "final"):
                 continue
-            q, op_open, op_pass, op_close, c = chan_def[name]
+            q, op_open, op_pass, op_close, closings = chan_def[name]
             if name[1] == s:
                 ent.append((il[("start",)], ir[name], op_open, 1.0))
             else:
@@ -329,9 +336,9 @@ def _build_mpo(nsites, onsite, pairs, sym=None):
         for name in nl:
             if name[0] in ("start", "final"):
                 continue
-            q, op_open, op_pass, op_close, c = chan_def[name]
-            if name[2] == s:
-                ent.append((il[name], ir[("final",)], op_close, c))
+            q, op_open, op_pass, op_close, closings = chan_def[name]
+            if s in closings:
+                ent.append((il[name], ir[("final",)], op_close, closings[s]))
         sites.append(MPOSite(ql, qr, ent))
     return MPO(sites, sym)
 

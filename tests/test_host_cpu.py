@@ -404,3 +404,33 @@ def test_three_equal_index_terms_equal_dense_density_assisted_hopping():
             pairs.append((j, i, 0.5 * (U13_IS[bi, bf, 2] + U13_IS[bi, bf, 3])))
     D = _dense_with_u13(n, [0.0], [0.0], 0.0, pairs)
     assert np.abs((M - M0) - D).max() < 1e-12
+
+
+def test_merged_channel_mpo_is_the_same_operator_on_a_narrower_bond():
+    """terms of one channel type that open on the same site share a level (models._build_mpo merge=True, the default):
+    same dense Hamiltonian as the reference-style uncompressed sum of per-term MPOs (`H += h`, src:439), fewer levels"""
+    t, u, J = [1.0, 0.3, 0.1], [4.0, 0.5, 0.2], [0.2, 0.1]
+    L = 5
+    sim = models.OB_Sim(t, u, 0.1, J, 1, 1, U13=[0.15, 0.05])
+    Hm = models.hamiltonian(sim, L)
+    onsite = {s: [("docc", u[0]), ("n", -0.1)] for s in range(L)}
+    pairs = []
+    for r, tr in enumerate(t, start=1):
+        pairs += [(i, i + r, "hop", -tr) for i in range(L - r)]
+    for r in range(1, len(u)):
+        pairs += [(i, i + r, "nn", u[r]) for i in range(L - r)]
+    for r, Jr in enumerate(J, start=1):
+        for i in range(L - r):
+            models._exchange(pairs, i, i + r, Jr)
+    for r, Ur in enumerate([0.15, 0.05], start=1):
+        for i in range(L - r):
+            models._assisted_hop(pairs, i, i + r, Ur)
+            models._assisted_hop(pairs, i + r, i, Ur)
+    Hu = models._build_mpo(L, onsite, pairs, merge=False)
+    Dm, Du = ompo.mpo_to_dense(_as_dict(Hm)), ompo.mpo_to_dense(_as_dict(Hu))
+    assert np.abs(Dm - Du).max() < 1e-12
+    wm, wu = max(len(W.right) for W in Hm), max(len(W.right) for W in Hu)
+    assert wm < wu and wm <= 0.7 * wu
+    # range-3 hopping alone: 3 levels per channel type instead of 6
+    H3 = models.hamiltonian(models.OB_Sim([1.0, 0.3, 0.1], [4.0]), 10)
+    assert len(H3[5].left) == 2 + 2 * 3
