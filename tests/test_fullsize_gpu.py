@@ -188,3 +188,39 @@ def test_sharded_apply_world1_is_bit_equal_to_the_unsharded_run(hip_ops):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_config5_L128_nnn_chi2048_centre_bond_against_the_oracle_and_properties(hip_ops):
+    """BASELINE configs[4]: L=128, hopping t = [1.0, 0.1] (examples/One_band.jl:25), U/t=4, chi=2048 -- on one GPU (the
+    8-GPU sharding of the same sweep is the code path of test_sharded_apply_world1_... and the gloo world-2 test).  The
+    grown state's centre bond is updated by the HIP engine and by the numpy oracle on the same downloaded tensors
+    (blocks of ~400 rows: the non-LDS SVD route, multi-slab GEMM tiles, range-2 MPO with the Z stage), then the
+    size-independent properties."""
+    from threadpoolctl import threadpool_limits
+    L = 128
+    H = models.hamiltonian(models.OB_Sim([1.0, 0.1], [4.0]), L)
+    eng = _grow(hip_ops, H, L, [(16, 6), (32, 3), (64, 2), (128, 2), (256, 1), (512, 1), (1024, 1)])
+    eng.chi_full, eng.lanczos_tol = 2048, 1e-10
+    E1 = eng.sweep()
+    E2 = eng.sweep()
+    assert max(eng.bond_dims()) == 2048 and E2 <= E1 + 1e-9 * abs(E1)
+    assert abs(E2 / L - (-0.5711)) < 1e-3
+    for b, s in eng.spectra.items():
+        assert abs(sum((c[1] + 1) * float(np.sum(v ** 2)) for c, v in s.items()) - 1.0) < 1e-12, b
+    i0 = L // 2 - 1
+    for i in range(0, i0):
+        eng.update_bond(i, +1, "right")
+    eng.lanczos_tol = 1e-12
+    with threadpool_limits(limits=1):
+        Er, spec = _oracle_on_bond(eng, H, i0, "left")
+    Eg = eng.update_bond(i0, +1, "left")
+    assert abs(Eg - Er) <= 1e-8 * abs(Er), (Eg, Er)
+    got = eng.spectrum(i0 + 1)
+    assert set(got) == set(spec)
+    for c, v in spec.items():
+        assert got[c].shape == np.asarray(v).shape and np.abs(got[c] - np.asarray(v)).max() <= 1e-8 * max(v), c
+    n = len(eng.theta(i0))
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    z = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    assert abs(np.vdot(z, eng.apply_heff(i0, x)) - np.vdot(eng.apply_heff(i0, z), x)) <= 1e-11 * abs(np.vdot(z, eng.apply_heff(i0, x)))
