@@ -245,9 +245,12 @@ def main():
         "value": sweep_s, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": sweep_s * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": "c128", "data": "synthetic (seeded random initial MPS, grown and converged in the untimed phase)",
-        "config": {"workload": f"one-band Hubbard chain L={L} U/t={args.U:g} half filling, fZ2xSU(2)xU(1), "
-                               f"two-site DMRG sweep (2L-3={2 * L - 3} bond updates) at chi={args.chi} "
-                               "(TensorKit dim units)",
+        "config": {"workload": {"one_band": f"one-band Hubbard chain L={L} U/t={args.U:g}",
+                                "one_band_nnn": f"one-band Hubbard chain L={L} t=[1.0, 0.1] U/t={args.U:g}",
+                                "polyacetylene": f"polyacetylene two-band model (examples/Polyacetylene.jl parameters), {L} chain sites"
+                                }.get(args.model, args.model)
+                               + f", half filling, fZ2xSU(2)xU(1), two-site DMRG sweep (2L-3={2 * L - 3} bond updates) "
+                                 f"at chi={args.chi} (TensorKit dim units)",
                    "model": args.model, "L": L, "chi": args.chi, "krylovdim": eng.krylovdim, "lanczos_tol": args.lanczos_tol,
                    "parallelism": "sector-parallel apply x%d" % world, "backend": args.backend},
         "energy_per_site": E / L,
