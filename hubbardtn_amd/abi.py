@@ -67,7 +67,8 @@ class Symmetry(C.Structure):
 
 class SvdOpts(C.Structure):
     """htn_svd_opts"""
-    _fields_ = [("split_elems", C.c_int32), ("pad", C.c_int32), ("rank_cut", C.c_double)]
+    _fields_ = [("split_elems", C.c_int32), ("sweeps_hint", C.c_int32), ("rank_cut", C.c_double),
+                ("sweeps_used", C.POINTER(C.c_int32))]
 
 
 class SweepOpts(C.Structure):

@@ -129,6 +129,7 @@ struct htn_mps {
     double energy = 0.0;
     std::map<int, Spectrum> spectra;
     std::map<int, std::pair<std::pair<int, double>, double>> cut_hint;      // bond -> ((chi, cutoff), smallest kept value)
+    std::map<int, int> sweeps_hint;     // bond -> outer Jacobi sweeps its large blocks needed last time (htn_svd_opts.sweeps_hint)
     std::vector<int32_t> idx_host;
 
     template <class T, class F>
@@ -422,9 +423,15 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
     // truncbelow(eta): everything below eta goes anyway.  truncdim(D): if the previous update of this bond (same D) was
     // limited by D, its smallest kept value is where the cut will fall again.  x is normalised: values compare across sweeps.
     htn_svd_opts so;
+    int32_t jac_used = 0;
     so.split_elems = o.svd_split_elems;
-    so.pad = 0;
+    so.sweeps_hint = 0;
     so.rank_cut = 0.0;
+    so.sweeps_used = &jac_used;
+    {       // the previous update of this bond tells how many outer sweeps the large blocks will need (speculation bound)
+        auto h = sweeps_hint.find(i + 1);
+        if (h != sweeps_hint.end()) so.sweeps_hint = h->second;
+    }
     if (o.rank_cut > 0.0) {
         double cut = 0.0;
         auto h = cut_hint.find(i + 1);
@@ -444,6 +451,7 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
                               o.jacobi_max_sweeps > 0 ? o.jacobi_max_sweeps : 40, o.jacobi_tol > 0.0 ? o.jacobi_tol : 1e-14,
                               info_dev, &so))
         return 1;
+    if (jac_used > 0) sweeps_hint[i + 1] = jac_used;
     std::vector<double> s_host(s_elems + (i_elems + 1) / 2);
     if (be->download(s_host.data(), S->p, sizeof(double) * s_elems + sizeof(int32_t) * i_elems)) return 1;
     const int32_t* info_h = (const int32_t*)(s_host.data() + s_elems);

@@ -908,7 +908,30 @@ __device__ __forceinline__ double2 cmulc(double2 ac, double2 b) {      // conj(a
     return make_double2(fma(ac.x, b.x, ac.y * b.y), fma(ac.x, b.y, -ac.y * b.x));
 }
 
+
+// rotation that annihilates the (lo, hi) entry g of a 2 x 2 Hermitian pivot [[aa, g], [conj g, bb]]: c = cos, cq = cos *
+// tan / |g|, dq = tan * |g|; identity (returns false) for dead slots, numerically zero columns and pairs already
+// orthogonal to tol.  No branches: cos from cos(2 theta) = |h| / w runs in parallel with the reciprocal that gives q.
+__device__ __forceinline__ bool jg_rotation(double aa, double bb, double2 g, bool live, double z2, double tol2,
+                                            double& c, double& cq, double& dq) {
+    const double g2 = fma(g.x, g.x, g.y * g.y);
+    const bool on = live && aa > z2 && bb > z2 && g2 > 0.0 && g2 > tol2 * aa * bb;
+    const double h = on ? bb - aa : 0.0, g2s = on ? g2 : 1.0, ah = fabs(h);
+    const double w2 = fma(h, h, 4.0 * g2s);
+    const double iw = fast_rsq(w2);
+    double q = 2.0 * fast_rcp(fma(w2, iw, ah));
+    q = h >= 0.0 ? q : -q;
+    const double c2 = fma(0.5 * ah, iw, 0.5);
+    const double cc = c2 * fast_rsq(c2);
+    c = on ? cc : 1.0;
+    cq = on ? cc * q : 0.0;
+    dq = on ? q * g2s : 0.0;
+    return on;
+}
+
 #define JG_LD 17
+#define JG_PS 9            // doubles per lane of the Gram partials (8 used): odd stride, no 16-way bank conflict
+#define JG_GU_ELEMS (4 * 64 * JG_PS / 2)        // complex128 elements of the G/U region (>= 4 * 16 * JG_LD; the partials alias it)
 __global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__ Vj,
                                                            const htn_svd_block* __restrict__ desc,
                                                            const int* __restrict__ large_ids,
@@ -940,15 +963,15 @@ __global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__
         const double2* __restrict__ src = X + (int64_t)(live ? col : 0) * mp;
         double2* dst = P + c * ldp;
         const int ne = mp >> 4;
-        for (int e0 = 0; e0 < ne; e0 += 8) {
-            double2 v[8];
+        for (int e0 = 0; e0 < ne; e0 += 16) {          // 16 requests in flight per lane: one round trip up to 256 rows
+            double2 v[16];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 16; ++e) {
                 const int row = r + 16 * (e0 + e);
                 v[e] = (live && e0 + e < ne) ? src[row] : make_double2(0.0, 0.0);
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
+            for (int e = 0; e < 16; ++e)
                 if (e0 + e < ne) dst[r + 16 * (e0 + e)] = v[e];
         }
     }
@@ -958,15 +981,27 @@ __global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__
         d4 g1 = {0.0, 0.0, 0.0, 0.0}, g2 = {0.0, 0.0, 0.0, 0.0}, mm = {0.0, 0.0, 0.0, 0.0};
         const double2* pc = P + l15 * ldp + l4;
         const int nit = mp >> 4;                     // k-steps of this wave: ks = wave + 4 it
-        double2 nxt = pc[4 * wave];
-        for (int it = 0; it < nit; ++it) {           // operand of the next step in flight during the 3 MFMAs
-            const double2 v = nxt;
-            if (it + 1 < nit) nxt = pc[4 * (wave + 4 * (it + 1))];
-            g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, v.x, g1, 0, 0, 0);
-            g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, v.y, g2, 0, 0, 0);
-            mm = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, v.y, mm, 0, 0, 0);      // M[a][b] = sum re_a im_b
+        // operands of four steps are fetched together, the next four are in flight during the 12 MFMAs
+        double2 nx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nx[u] = u < nit ? pc[4 * (wave + 4 * u)] : make_double2(0.0, 0.0);
+        for (int it0 = 0; it0 < nit; it0 += 4) {
+            double2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = nx[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (it0 + 4 + u < nit) nx[u] = pc[4 * (wave + 4 * (it0 + 4 + u))];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (it0 + u < nit) {                 // wave-uniform
+                    g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u].x, v[u].x, g1, 0, 0, 0);
+                    g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u].y, v[u].y, g2, 0, 0, 0);
+                    mm = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u].x, v[u].y, mm, 0, 0, 0);      // M[a][b] = sum re_a im_b
+                }
+            }
         }
-        double* part = (double*)GU + (wave * 64 + lane) * 8;
+        double* part = (double*)GU + (wave * 64 + lane) * JG_PS;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             part[r] = g1[r] + g2[r];
@@ -977,14 +1012,14 @@ __global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__
     const int ei = tid >> 4, ej = tid & 15;
     {
         // accumulator element (row = l4 + 4 reg, col = l15): G[i][j] sits in lane j + 16 (i & 3), reg i >> 2
-        const double* pa = (const double*)GU + (ej + 16 * (ei & 3)) * 8 + (ei >> 2);
-        const double* pb = (const double*)GU + (ei + 16 * (ej & 3)) * 8 + 4 + (ej >> 2);
+        const double* pa = (const double*)GU + (ej + 16 * (ei & 3)) * JG_PS + (ei >> 2);
+        const double* pb = (const double*)GU + (ei + 16 * (ej & 3)) * JG_PS + 4 + (ej >> 2);
         double gr = 0.0, mij = 0.0, mji = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {               // fixed order: deterministic
-            gr += pa[w * 512];
-            mij += pa[w * 512 + 4];
-            mji += pb[w * 512];
+            gr += pa[w * 64 * JG_PS];
+            mij += pa[w * 64 * JG_PS + 4];
+            mji += pb[w * 64 * JG_PS];
         }
         __syncthreads();                            // partials consumed; the region becomes G / U
         GU[ei * JG_LD + ej] = make_double2(gr, mij - mji);
@@ -1034,40 +1069,11 @@ __global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__
             const double2 gij = Gc[ei * JG_LD + ej], gijb = Gc[ei * JG_LD + jb];
             const double2 gibj = Gc[ib * JG_LD + ej], gibjb = Gc[ib * JG_LD + jb];
             const double2 uij = Uc[ei * JG_LD + ej], uijb = Uc[ei * JG_LD + jb];
-            // J = [[c, c q g], [-c q conj(g), c]] on (lo, hi), q = tan / |g|: real diagonal, no phase division;
-            // cos from cos(2 theta) = |h| / w runs in parallel with the reciprocal that gives q
-            double ci = 1.0, cqi = 0.0, dqi = 0.0, cj = 1.0, cqj = 0.0;
-            bool oni = false;
-            {
-                const double g2 = fma(ig.x, ig.x, ig.y * ig.y);
-                if (((livemask >> ilo) & (livemask >> ihi) & 1u) && iaa > z2 && ibb > z2 && g2 > 0.0 &&
-                    g2 > tol2 * iaa * ibb) {
-                    const double h = ibb - iaa, ah = fabs(h);
-                    const double w2 = fma(h, h, 4.0 * g2);
-                    const double iw = fast_rsq(w2);
-                    double q = 2.0 * fast_rcp(fma(w2, iw, ah));
-                    q = h >= 0.0 ? q : -q;
-                    const double c2 = fma(0.5 * ah, iw, 0.5);
-                    ci = c2 * fast_rsq(c2);
-                    cqi = ci * q;
-                    dqi = q * g2;
-                    oni = true;
-                }
-            }
-            {
-                const double g2 = fma(jg.x, jg.x, jg.y * jg.y);
-                if (((livemask >> jlo) & (livemask >> jhi) & 1u) && jaa > z2 && jbb > z2 && g2 > 0.0 &&
-                    g2 > tol2 * jaa * jbb) {
-                    const double h = jbb - jaa, ah = fabs(h);
-                    const double w2 = fma(h, h, 4.0 * g2);
-                    const double iw = fast_rsq(w2);
-                    double q = 2.0 * fast_rcp(fma(w2, iw, ah));
-                    q = h >= 0.0 ? q : -q;
-                    const double c2 = fma(0.5 * ah, iw, 0.5);
-                    cj = c2 * fast_rsq(c2);
-                    cqj = cj * q;
-                }
-            }
+            // J = [[c, c q g], [-c q conj(g), c]] on (lo, hi), q = tan / |g|: real diagonal, no phase division.
+            // Both rotations are computed branch-free (jg_rotation) so that their two dependent chains interleave.
+            double ci, cqi, dqi, cj, cqj, dqj;
+            const bool oni = jg_rotation(iaa, ibb, ig, ((livemask >> ilo) & (livemask >> ihi) & 1u) != 0, z2, tol2, ci, cqi, dqi);
+            jg_rotation(jaa, jbb, jg, ((livemask >> jlo) & (livemask >> jhi) & 1u) != 0, z2, tol2, cj, cqj, dqj);
             // column j of J: J[j][j] = c, J[jb][j] = -cq conj(g) if j is the lower index, +cq g if the upper
             const double2 jpj = ej == jlo ? make_double2(-cqj * jg.x, cqj * jg.y) : make_double2(cqj * jg.x, cqj * jg.y);
             const double2 ipi = ei == ilo ? make_double2(-cqi * ig.x, cqi * ig.y) : make_double2(cqi * ig.x, cqi * ig.y);
@@ -1077,9 +1083,11 @@ __global__ __launch_bounds__(256) void k_jacobi_pairs_gram(double2* __restrict__
             const double2 Tibj = make_double2(fma(cj, gibj.x, t2.x), fma(cj, gibj.y, t2.y));
             t2 = cmulc(ipi, Tibj);
             double2 gn = make_double2(fma(ci, Tij.x, t2.x), fma(ci, Tij.y, t2.y));
-            if (oni) {      // pivot block by Rutishauser's formulas: a' = a - t|g|, b' = b + t|g|, off-diagonal 0
-                if (ej == ei) gn = make_double2(ei == ilo ? iaa - dqi : ibb + dqi, 0.0);
-                else if (ej == ib) gn = make_double2(0.0, 0.0);
+            {               // pivot block by Rutishauser's formulas: a' = a - t|g|, b' = b + t|g|, off-diagonal 0
+                const double dg = ei == ilo ? iaa - dqi : ibb + dqi;
+                const bool pd = oni && ej == ei, po = oni && ej == ib;
+                gn.x = pd ? dg : (po ? 0.0 : gn.x);
+                gn.y = (pd || po) ? 0.0 : gn.y;
             }
             t2 = cmul(uijb, jpj);
             Gn[ei * JG_LD + ej] = gn;
@@ -1245,7 +1253,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
             HIP_TRY(hipFuncSetAttribute((const void*)k_qr_large, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         16 * (64 * JAC_MAXEL + 1) * (int)sizeof(double2)));
             HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_pairs_gram, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (16 * (64 * JAC_MAXEL + 1) + 4 * 16 * JG_LD) * (int)sizeof(double2)));
+                                        (16 * (64 * JAC_MAXEL + 1) + JG_GU_ELEMS) * (int)sizeof(double2)));
             attr_set[dev] = true;
         }
     }
@@ -1260,6 +1268,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
             const int mp = gsx * ((D.m + gsx - 1) / gsx);
             if ((int64_t)mp * D.n > large_min) large.push_back(b);
         }
+    if (opts && opts->sweeps_used) *opts->sweeps_used = 0;
     if (large.empty()) {
         hipLaunchKernelGGL(k_jacobi_svd, dim3(n_blocks), dim3(JAC_THREADS), lds_elems * sizeof(double2), st, (double2*)G,
                            (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)nullptr,
@@ -1378,7 +1387,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         }
     }
     if (n_items) HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(JacPairItem) * n_items, hipMemcpyHostToDevice, st));
-    const size_t gram_lds_bytes = (size_t)(16 * (max_mp + 1) + 4 * 16 * JG_LD) * sizeof(double2);
+    const size_t gram_lds_bytes = (size_t)(16 * (max_mp + 1) + JG_GU_ELEMS) * sizeof(double2);
     // sweeps are enqueued one ahead of the host's knowledge (depth-1 pipeline, like htn_lanczos_z): the device
     // decides convergence itself (k_jacobi_check), the host only learns when to stop enqueuing
     HIP_TRY(hipMemsetAsync(d_ratio, 0, 8 * nl, st));
@@ -1393,12 +1402,31 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
                            (int*)h_active + sweep);
         return hipEventRecord(g_js.ev_sweep[sweep & 1], st);
     };
-    if (max_sweeps > 0) HIP_TRY(enqueue_sweep(0));
-    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-        if (sweep + 1 < max_sweeps) HIP_TRY(enqueue_sweep(sweep + 1));
-        HIP_TRY(hipEventSynchronize(g_js.ev_sweep[sweep & 1]));
-        if (h_active[sweep] == 0) break;
+    // Speculation is bounded by the caller's expectation (htn_svd_opts.sweeps_hint, normally what the previous update of
+    // the same bond needed): the sweep expected to be the last is NOT followed by a speculative one -- an outer sweep that
+    // finds every block done still costs its launches (26 x 4.5 us at chi = 1024).  A wrong hint costs one host round trip
+    // per extra sweep instead.
+    const int hint = opts && opts->sweeps_hint > 0 ? opts->sweeps_hint : 0;
+    int enq = 0, used = 0;
+    if (max_sweeps > 0) {
+        HIP_TRY(enqueue_sweep(0));
+        enq = 1;
     }
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        const bool expect_last = hint > 0 && sweep + 1 >= hint;
+        if (sweep + 1 < max_sweeps && !expect_last && enq == sweep + 1) {
+            HIP_TRY(enqueue_sweep(sweep + 1));
+            ++enq;
+        }
+        HIP_TRY(hipEventSynchronize(g_js.ev_sweep[sweep & 1]));
+        used = sweep + 1;
+        if (h_active[sweep] == 0) break;
+        if (sweep + 1 < max_sweeps && enq == sweep + 1) {
+            HIP_TRY(enqueue_sweep(sweep + 1));
+            ++enq;
+        }
+    }
+    if (opts && opts->sweeps_used) *opts->sweeps_used = used;
     HIP_TRY(hipStreamWaitEvent(st, g_js.ev_join, 0));
     hipLaunchKernelGGL(k_jacobi_finish, dim3(nl), dim3(JAC_THREADS), 0, st, (double2*)G, (const double2*)Vj, S, desc,
                        d_ids, d_perm, d_sw, d_done, info_dev);

@@ -249,14 +249,19 @@ class HipOps:
             self.event_log.append(("matvec_ms", ms.value, nmv.value))
         return eig.value, nmv.value, res.value
 
-    def jacobi_svd(self, G, Vj, S, desc_dev, nblocks, max_m, max_sweeps, tol, info, desc_host=None, split=0, rank_cut=0.0):
+    def jacobi_svd(self, G, Vj, S, desc_dev, nblocks, max_m, max_sweeps, tol, info, desc_host=None, split=0, rank_cut=0.0,
+                   sweeps_hint=0):
         """split: elements of R^H above which a block takes the large-block SVD path (0 = default);
-        rank_cut: absolute singular-value cut of the large blocks' rank-revealing QR (0 = off).  Per call (ABI 2)."""
+        rank_cut: absolute singular-value cut of the large blocks' rank-revealing QR (0 = off); sweeps_hint: expected outer
+        sweeps of the large-block path (bounds the speculative enqueue).  Per call (ABI 2).  Returns the outer sweeps the
+        large-block path used (0: no block took it)."""
         hp = C.c_void_p(desc_host.ctypes.data) if desc_host is not None else C.c_void_p(0)
-        opts = abi.SvdOpts(int(split), 0, float(rank_cut))
+        used = C.c_int32(0)
+        opts = abi.SvdOpts(int(split), int(sweeps_hint), float(rank_cut), C.pointer(used))
         abi.check(self.lib, self.lib.htn_jacobi_svd_z(self._p(G), self._p(Vj), self._p(S), self._p(desc_dev), hp,
                                                       nblocks, max_m, max_sweeps, float(tol), self._p(info),
                                                       C.byref(opts), self._stream()), "htn_jacobi_svd_z")
+        return used.value
 
     def batched_copy(self, dst, src, idx, scl, items_dev, nitems, gscale):
         if nitems == 0:

@@ -171,12 +171,19 @@ typedef struct {
  *                 not yet factorised is below rank_cut^2 (it bounds every remaining singular value), the remaining
  *                 rows of R are dropped, the tournament runs on the rank found, and the dropped singular values are
  *                 reported as 0.  <= 0 = off (default).  Kept singular values then move by at most
- *                 rank_cut^2 / (2 sigma) (interlacing). */
+ *                 rank_cut^2 / (2 sigma) (interlacing).
+ *   sweeps_hint : outer sweeps the large-block path is expected to need (normally `*sweeps_used` of the previous call
+ *                 for the same bond); the sweep expected to be the last is not followed by a speculatively enqueued
+ *                 one.  <= 0: unknown, every sweep is enqueued one ahead of the host's knowledge.  Results do not
+ *                 depend on it.
+ *   sweeps_used : host pointer or NULL; receives the number of outer sweeps of the large-block path after which every
+ *                 large block had converged (0 when no block took that path). */
 typedef struct {
     int32_t split_elems;
-    int32_t pad;
+    int32_t sweeps_hint;
     double rank_cut;
-} htn_svd_opts;
+    int32_t* sweeps_used;
+} htn_svd_opts;         /* 24 bytes */
 int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_block* desc, const htn_svd_block* desc_host,
                      int32_t n_blocks, int32_t max_m_host, int32_t max_sweeps, double tol, int32_t* info_dev,
                      const htn_svd_opts* opts, void* stream);

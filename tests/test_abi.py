@@ -49,6 +49,7 @@ def test_struct_layouts_match_header():
     assert abi.TILE_DT.itemsize == 64 and abi.SEG_DT.itemsize == 64
     assert abi.SVD_DT.itemsize == 40 and abi.COPY_DT.itemsize == 64
     assert ctypes.sizeof(abi.GemmLaunch) == 8 * 8 + 8 + 8 + 4 + 4
+    assert ctypes.sizeof(abi.SvdOpts) == 24                 # htn_svd_opts
     assert abi.TILE_DT.fields["seg_begin"][1] == 32 and abi.SEG_DT.fields["alpha_re"][1] == 48
 
 
