@@ -1,17 +1,24 @@
 // grouped, segmented complex128 GEMM on v_mfma_f64_16x16x4_f64 (libhubbardtn_hip.so)
 //
-// Regime: one H_eff apply at chi = 512..2048 is 10^7..10^9 flops spread over a few
-// hundred ragged output tiles -- far too little to fill 256 CUs by output tiles alone, and the f64
-// MFMA is slow (64 clk per 16x16x4), so the critical path is ONE tile's K loop.  The kernel therefore
-// spends a whole 16-wave workgroup on each <=32x32 tile: 4 wave-quads take the tile's K slabs
-// round-robin (intra-workgroup split-K), each quad owns private LDS slab buffers, the next slab's
-// global loads are issued before the current slab's MFMAs (register prefetch), and the 4 partial
-// accumulators are summed through LDS in a fixed order (deterministic).
+// Regime: one H_eff apply at chi = 512..2048 is 10^8..10^9 flops spread over a few hundred ragged
+// output tiles (<= 32 x 32; mean 18 x 18 at chi = 1024: the sector blocks are 12, 23, 24, 53 ... wide) whose K loops are
+// lists of 16-deep slabs gathered from different operand blocks.  The f64 MFMA is slow (64 clk per 16x16x4), so what
+// bounds a launch is MFMA ISSUE per CU plus whatever latency is not hidden behind it.
 //
-// Each segment contributes alpha * op(A) * op(B); alpha is folded into A while staging, so every
-// segment accumulates into the same MFMA accumulators.  K slabs are 16 deep, staged as separate
-// re / im planes.  Each wave owns a 16x16 quadrant and computes it TRANSPOSED (operand roles swapped)
-// so that consecutive lanes hold consecutive rows of the column-major output (256-byte store runs).
+// One 4-wave workgroup per tile, several workgroups resident per CU (no LDS staging, ~12 KiB LDS for the epilogue):
+//   * a wave feeds its MFMAs STRAIGHT from global memory / L2: lane (l15, l4) of the A operand loads element
+//     [row l15][k = 4 ks + l4] of the slab, i.e. exactly the register the MFMA wants -- no LDS round trip, no
+//     workgroup barrier inside the K loop; the next slab's 8 loads are in flight during the current slab's 16 MFMAs and
+//     the other resident waves of the SIMD cover the rest of the latency;
+//   * only the 16 x 16 quadrants a tile really has are computed: a tile with m, n <= 16 is ONE quadrant and its four
+//     waves split the K slabs four ways; 16 < m <= 32, n <= 16 (or the transpose): two quadrants x two-way split; a full
+//     tile: four quadrants, every wave walks all slabs.  (The previous kernel issued the full 32 x 32 x 16 MFMA set for
+//     every slab: 40 % of the issued MFMAs were useful at chi = 1024.)
+//   * partial accumulators of the K groups are summed through LDS in a fixed order (deterministic).
+//
+// Each segment contributes alpha * op(A) * op(B); alpha and the conjugations are applied to the operand registers just
+// before the MFMAs (the loads stay in flight until then).  Each wave computes its quadrant TRANSPOSED (operand roles
+// swapped) so that consecutive lanes hold consecutive rows of the column-major output (256-byte store runs).
 //
 // f64 MFMA lane maps (cdna_hip_programming.md section 3):
 //   A operand: lane l holds Aop[i = l & 15][k = l >> 4]     B operand: Bop[k = l >> 4][j = l & 15]
@@ -24,32 +31,20 @@ struct BufTable {
 };
 
 #define KB 16         // K slab depth
-#define NQ HTN_GEMM_QUADS   // wave-quads per workgroup (intra-workgroup split-K ways)
-#define LDS_LD 48     // padded leading dimension (doubles) of a 32-wide slab row: 48 = 16 mod 32 keeps
-                      // the two k-rows read by one 32-lane group on disjoint banks (ds_read_b64)
-// Row kk is additionally rotated by kk inside its 32 doubles: a k-contiguous staging pass (16 lanes
-// writing 16 different kk at one idx) then hits 16 different banks instead of one.
-#define LDS_AT(kk, idx) ((kk) * LDS_LD + (((idx) + (kk)) & 31))
-#define SLAB (KB * LDS_LD)
 
-struct Slab {             // what one thread stages for one K slab: 2 elements of A, 2 of B
-    double2 a[2], b[2];
-};
-
-// cursor of one quad over the tile's GEMM segments: (segment index, k offset)
+// cursor of one wave over the tile's GEMM segments: (segment index, k offset)
 struct Cursor {
     int s, k0;
 };
 
 // move the cursor forward by `nslabs` K slabs over the flat slab sequence of the tile's GEMM segments
-__device__ __forceinline__ void advance(Cursor& c, int nslabs, const htn_seg* __restrict__ segs, int seg_begin,
-                                        int n_gemm, bool presplit) {
+__device__ __forceinline__ void advance(Cursor& c, int nslabs, const htn_seg* __restrict__ sg, int n_gemm, bool presplit) {
     if (presplit) {          // every GEMM segment is one slab (k <= 16): no descriptor reads needed to walk
         c.s += nslabs;
         return;
     }
     while (nslabs > 0 && c.s < n_gemm) {
-        const int K = segs[seg_begin + c.s].k;
+        const int K = sg[c.s].k;
         const int rem = (K - c.k0 + KB - 1) / KB;
         if (nslabs < rem) {
             c.k0 += nslabs * KB;
@@ -62,223 +57,178 @@ __device__ __forceinline__ void advance(Cursor& c, int nslabs, const htn_seg* __
     }
 }
 
-__device__ __forceinline__ void load_slab(Slab& r, const BufTable& bufs, const htn_tile& T, const htn_seg& S,
-                                          const Cursor& c, bool valid, int tq) {
-    r.a[0] = r.a[1] = r.b[0] = r.b[1] = make_double2(0.0, 0.0);
-    if (!valid) return;
-    const double2* __restrict__ Ap = bufs.p[S.buf_a] + S.a_off;
-    const double2* __restrict__ Bp = bufs.p[S.buf_b] + S.b_off;
-    const int K = S.k;
+// the MFMA operands of one wave for one K slab, as loaded (alpha / conjugation / K mask still to be applied).  Everything
+// but a[] and b[] is wave-uniform and lives in SGPRs.
+struct Ops {
+    double2 a[4], b[4];       // [k step]: A[row l15][k = 4 ks + l4], B[k = 4 ks + l4][col l15]
+    double c1, c2, c3, c4;    // alpha * op(a):  re = c1 a.x + c2 a.y,  im = c3 a.y + c4 a.x
+    int ksteps;               // 0: past the last slab
+    int kleft;                // k extent of the slab (1..16): lanes with 4 ks + l4 >= kleft contribute zero
+    bool conj_b;
+};
+
+__device__ __forceinline__ double sflip(double x, bool neg) {
+    return __longlong_as_double(__double_as_longlong(x) ^ (neg ? (long long)0x8000000000000000ull : 0ll));
+}
+
+// Loads are branch-free and always in bounds: rows / columns beyond the tile edge re-read the edge (their products land in
+// accumulator rows / columns that are never stored), k beyond the slab re-reads its last k (masked to zero at use).
+// Addressing: scalar base (buffer + block offset + slab start) + ONE 32-bit lane offset per load.
+__device__ __forceinline__ void load_ops(Ops& r, const BufTable& bufs, const htn_seg& S, const Cursor& c,
+                                         bool valid, int arow, int bcol, int l4) {
+    // NO control flow around the loads: exactly 8 per call, so that the compiler can count them (s_waitcnt vmcnt(8 (D - 1))
+    // in front of a slab's MFMAs instead of vmcnt(0), which would wait for the prefetches just issued as well).  An invalid
+    // call (past the last slab) re-reads the last valid slab and marks the set unused (ksteps = 0).
+    const int k0 = valid ? c.k0 : 0;
+    int kleft = S.k - k0 < KB ? S.k - k0 : KB;
+    kleft = kleft > 0 ? kleft : 1;
+    r.kleft = kleft;
+    r.ksteps = valid ? (kleft + 3) >> 2 : 0;
+    const bool an = S.op_a == HTN_OP_N, bn = S.op_b == HTN_OP_N, ca = S.op_a == HTN_OP_C;
+    r.conj_b = S.op_b == HTN_OP_C;
+    r.c1 = S.alpha_re;                               // (sign flips on the bit pattern: SALU, the values stay in SGPRs)
+    r.c2 = sflip(S.alpha_im, !ca);
+    r.c3 = sflip(S.alpha_re, ca);
+    r.c4 = S.alpha_im;
+    const int a_sr = an ? 1 : S.lda, a_sk = an ? S.lda : 1;           // element strides of op(A): row, k
+    const int b_sc = bn ? S.ldb : 1, b_sk = bn ? 1 : S.ldb;           //                  op(B): column, k
+    const char* __restrict__ Ab = (const char*)(bufs.p[S.buf_a] + S.a_off + (int64_t)k0 * a_sk);
+    const char* __restrict__ Bb = (const char*)(bufs.p[S.buf_b] + S.b_off + (int64_t)k0 * b_sk);
+    const unsigned ar = (unsigned)(arow * a_sr), bc = (unsigned)(bcol * b_sc);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        int r_, kk;
-        if (S.op_a == HTN_OP_N) {       // rows contiguous in memory
-            r_ = tq & 31;
-            kk = (tq >> 5) + 8 * it;
-        } else {                        // k contiguous in memory
-            kk = tq & 15;
-            r_ = (tq >> 4) + 16 * it;
-        }
-        if (r_ < T.m && c.k0 + kk < K) {
-            double2 a;
-            if (S.op_a == HTN_OP_N) a = Ap[(int64_t)(T.row0 + r_) + (int64_t)(c.k0 + kk) * S.lda];
-            else {
-                a = Ap[(int64_t)(c.k0 + kk) + (int64_t)(T.row0 + r_) * S.lda];
-                if (S.op_a == HTN_OP_C) a.y = -a.y;
-            }
-            r.a[it] = make_double2(S.alpha_re * a.x - S.alpha_im * a.y, S.alpha_re * a.y + S.alpha_im * a.x);
-        }
-        int c_, kb;
-        if (S.op_b == HTN_OP_N) {       // k contiguous
-            kb = tq & 15;
-            c_ = (tq >> 4) + 16 * it;
-        } else {                        // columns contiguous
-            c_ = tq & 31;
-            kb = (tq >> 5) + 8 * it;
-        }
-        if (c_ < T.n && c.k0 + kb < K) {
-            double2 b;
-            if (S.op_b == HTN_OP_N) b = Bp[(int64_t)(c.k0 + kb) + (int64_t)(T.col0 + c_) * S.ldb];
-            else {
-                b = Bp[(int64_t)(T.col0 + c_) + (int64_t)(c.k0 + kb) * S.ldb];
-                if (S.op_b == HTN_OP_C) b.y = -b.y;
-            }
-            r.b[it] = b;
+    for (int ks = 0; ks < 4; ++ks) {
+        const int kl = min(4 * ks + l4, kleft - 1);
+        r.a[ks] = *(const double2*)(Ab + (size_t)((ar + (unsigned)(kl * a_sk)) << 4));
+        r.b[ks] = *(const double2*)(Bb + (size_t)((bc + (unsigned)(kl * b_sk)) << 4));
+    }
+}
+
+__device__ __forceinline__ void mfma_ops(const Ops& r, d4& acc_re, d4& acc_im, int l4) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (ks < r.ksteps) {                         // wave-uniform
+            const bool live = 4 * ks + l4 < r.kleft;
+            const double ax = live ? r.a[ks].x : 0.0, ay = live ? r.a[ks].y : 0.0;
+            const double a_re = fma(r.c1, ax, r.c2 * ay), a_im = fma(r.c3, ay, r.c4 * ax);
+            const double bx = r.b[ks].x, by = r.conj_b ? -r.b[ks].y : r.b[ks].y;
+            acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(bx, a_re, acc_re, 0, 0, 0);
+            acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-by, a_im, acc_re, 0, 0, 0);
+            acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(bx, a_im, acc_im, 0, 0, 0);
+            acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(by, a_re, acc_im, 0, 0, 0);
         }
     }
 }
 
-__device__ __forceinline__ void store_slab(const Slab& r, double* __restrict__ lds, int op_a, int op_b, int tq) {
-    // lds: [A_re | A_im | B_re | B_im] of this quad
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        int r_, kk;
-        if (op_a == HTN_OP_N) {
-            r_ = tq & 31;
-            kk = (tq >> 5) + 8 * it;
-        } else {
-            kk = tq & 15;
-            r_ = (tq >> 4) + 16 * it;
-        }
-        lds[0 * SLAB + LDS_AT(kk, r_)] = r.a[it].x;
-        lds[1 * SLAB + LDS_AT(kk, r_)] = r.a[it].y;
-        int c_, kb;
-        if (op_b == HTN_OP_N) {
-            kb = tq & 15;
-            c_ = (tq >> 4) + 16 * it;
-        } else {
-            c_ = tq & 31;
-            kb = (tq >> 5) + 8 * it;
-        }
-        lds[2 * SLAB + LDS_AT(kb, c_)] = r.b[it].x;
-        lds[3 * SLAB + LDS_AT(kb, c_)] = r.b[it].y;
-    }
+
+// Segment descriptors are staged ONCE per workgroup in LDS (coalesced vector loads) and read from there per slab: a scalar
+// load of a cold 64-byte descriptor costs ~0.6 us and, SMEM returning out of order, cannot be kept more than one deep --
+// it was the pace-maker of the K loop (measured: the kernel with loads and MFMAs compiled out still took 11..18 us).
+#define GEMM_DESC_MAX 64       // descriptors staged per tile (4 KiB); longer lists read the rest through the scalar cache
+__device__ __forceinline__ htn_seg read_seg(const htn_seg* s_desc, const htn_seg* __restrict__ sg, int idx, int n_staged) {
+    if (idx >= n_staged) return sg[idx];             // wave-uniform
+    const uint4* p = (const uint4*)(s_desc + idx);
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    auto u = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    auto i64 = [&](unsigned lo, unsigned hi) { return (int64_t)(((unsigned long long)u(hi) << 32) | u(lo)); };
+    htn_seg S;
+    S.a_off = i64(q0.x, q0.y);
+    S.b_off = i64(q0.z, q0.w);
+    S.buf_a = (int)u(q1.x), S.buf_b = (int)u(q1.y), S.lda = (int)u(q1.z), S.ldb = (int)u(q1.w);
+    S.k = (int)u(q2.x), S.op_a = (int)u(q2.y), S.op_b = (int)u(q2.z), S.type = 0;
+    S.alpha_re = __longlong_as_double(i64(q3.x, q3.y));
+    S.alpha_im = __longlong_as_double(i64(q3.z, q3.w));
+    return S;
 }
 
-__global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, const htn_tile* __restrict__ tiles,
-                                                             const htn_seg* __restrict__ segs) {
-    __shared__ double lds_all[NQ * 4 * SLAB];        // 4 quads x (A_re, A_im, B_re, B_im) = 96 KiB
+#define GEMM_WAVES 4
+#ifdef HTN_GEMM_PROF       // diagnostic build only (tools/gemm_prof.py): per-workgroup start / end stamps and placement
+__device__ long long g_gemm_prof[8192 * 6];
+extern "C" int htn_gemm_prof_dump(long long* out, int n) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_prof), sizeof(long long) * 6 * (size_t)(n < 8192 ? n : 8192)));
+    return 0;
+}
+#endif
+#ifndef GEMM_DEPTH
+#define GEMM_DEPTH 2     // K slabs in registers per wave (32 VGPRs each)
+#endif
+#ifndef GEMM_MINOCC
+#define GEMM_MINOCC 4     // workgroups (one wave per SIMD each) co-resident per CU
+#endif
+__global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_MINOCC) void k_grouped_gemm_z(BufTable bufs, const htn_tile* __restrict__ tiles,
+                                                                       const htn_seg* __restrict__ segs) {
+    __shared__ double red[3 * 64 * 8];      // partial accumulators of the K groups 1..3 (12 KiB); also the split-K flag
+    __shared__ htn_seg s_desc[GEMM_DESC_MAX];
 
+#ifdef HTN_GEMM_PROF
+    const long long prof_t0 = wall_clock64();
+    const long long prof_c0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
     const htn_tile T = tiles[blockIdx.x];
-    const int tid = threadIdx.x;
-    const int q = tid >> 8;               // wave-quad
-    const int tq = tid & 255;             // thread within quad
-    const int lane = tid & 63;
-    const int wave = tq >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    double* __restrict__ lds = lds_all + q * 4 * SLAB;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    // (readfirstlane: the wave index, hence the K group, the cursor and every segment descriptor field, lives in SGPRs)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // quadrants the tile has, K groups the waves form: wave = grp * nquad + quad
+    const int qr = T.m > 16 ? 2 : 1, qc = T.n > 16 ? 2 : 1, nquad = qr * qc, ngrp = GEMM_WAVES / nquad;
+    const int quad = wave % nquad, grp = wave / nquad;
+    const int wr = qr == 2 ? (qc == 2 ? quad >> 1 : quad) : 0, wc = qc == 2 ? (quad & 1) : 0;
     const int n_gemm = T.seg_count - T.pad[0];     // GEMM segments first, then pad[0] COPY segments
+    const bool presplit = T.pad[1] != 0;
+    const htn_seg* __restrict__ sg = segs + T.seg_begin;
+    const int n_staged = n_gemm < GEMM_DESC_MAX ? n_gemm : GEMM_DESC_MAX;
+    for (int i = tid; i < 4 * n_staged; i += 64 * GEMM_WAVES) ((uint4*)s_desc)[i] = ((const uint4*)sg)[i];
+    __syncthreads();
+    const int orow = wr * 16 + l15;                // this lane's outputs are C[r0 + orow][c0 + wc 16 + l4 + 4 r]
+    // operand row / column of this lane, clamped to the tile edge (see load_ops)
+    const int arow = T.row0 + (orow < T.m ? orow : T.m - 1), bcol = T.col0 + (wc * 16 + l15 < T.n ? wc * 16 + l15 : T.n - 1);
 
     d4 acc_re = {0.0, 0.0, 0.0, 0.0};
     d4 acc_im = {0.0, 0.0, 0.0, 0.0};
 
-    const bool presplit = T.pad[1] != 0;
-    if (presplit) {
-        // ---- pre-split tiles (what the planner emits): every GEMM segment IS one K slab, so quad q's slab t is
-        // segment q + NQ t and no cursor walk is needed.  Two slabs are in flight in registers (loaded two rounds
-        // before they are staged): the operand fetch -- L2 / Infinity-Cache latency, ~2-3 us under load -- hides
-        // behind TWO rounds of MFMAs instead of one (SQ_VALU_MFMA_BUSY was 28 % of the busy CU time with one).
-        const htn_seg* __restrict__ sg = segs + T.seg_begin;
-        const Cursor c0 = {0, 0};
-        int j = q;                                         // segment of the slab staged next
-        htn_seg D = {};
-        Slab r0, r1;
-        bool v0 = j < n_gemm, v1 = j + NQ < n_gemm, vn = j + 2 * NQ < n_gemm;
-        int oa0 = 0, ob0 = 0, k0 = 0, oa1 = 0, ob1 = 0, k1 = 0;
-        if (v0) {
-            D = sg[j];
-            oa0 = D.op_a, ob0 = D.op_b, k0 = D.k;
-        }
-        load_slab(r0, bufs, T, D, c0, v0, tq);
-        if (v1) {
-            D = sg[j + NQ];
-            oa1 = D.op_a, ob1 = D.op_b, k1 = D.k;
-        }
-        load_slab(r1, bufs, T, D, c0, v1, tq);
-        if (vn) D = sg[j + 2 * NQ];                          // descriptor of the slab loaded in the first round
-        bool any = n_gemm > 0;
-#define HTN_ROUND(RS, OA, OB, KK, VV)                                                                        \
-        {                                                                                                    \
-            store_slab(RS, lds, VV ? OA : 0, VV ? OB : 0, tq);                                               \
-            __syncthreads();                                                                                 \
-            const bool cur_valid = VV;                                                                       \
-            const int kleft = VV ? KK : 0;                                                                   \
-            /* the register slab just staged is free: fetch the slab two rounds ahead into it */            \
-            VV = vn;                                                                                         \
-            if (vn) OA = D.op_a, OB = D.op_b, KK = D.k;                                                      \
-            load_slab(RS, bufs, T, D, c0, vn, tq);                                                           \
-            j += NQ;                                                                                         \
-            vn = j + 2 * NQ < n_gemm;                                                                        \
-            if (cur_valid) {                                                                                 \
-                const int ksteps = kleft >= KB ? KB / 4 : (kleft + 3) >> 2;                                  \
-                for (int ks = 0; ks < ksteps; ++ks) {                                                        \
-                    const int kk = ks * 4 + l4;                                                              \
-                    const double b_re = lds[2 * SLAB + LDS_AT(kk, wc * 16 + l15)];                           \
-                    const double b_im = lds[3 * SLAB + LDS_AT(kk, wc * 16 + l15)];                           \
-                    const double a_re = lds[0 * SLAB + LDS_AT(kk, wr * 16 + l15)];                           \
-                    const double a_im = lds[1 * SLAB + LDS_AT(kk, wr * 16 + l15)];                           \
-                    acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_re, acc_re, 0, 0, 0);              \
-                    acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-b_im, a_im, acc_re, 0, 0, 0);             \
-                    acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_im, acc_im, 0, 0, 0);              \
-                    acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_im, a_re, acc_im, 0, 0, 0);              \
-                }                                                                                            \
-            }                                                                                                \
-            /* descriptor of the slab the NEXT round loads: after the MFMA phase (scalar loads share lgkmcnt with  \
-               the LDS operand reads), its latency hides behind the barrier and the next staging */         \
-            if (vn) D = sg[j + 2 * NQ];                                                                      \
-        }
-        while (any) {
-            HTN_ROUND(r0, oa0, ob0, k0, v0)
-            any = __syncthreads_or(v1 ? 1 : 0) != 0;          // is there a slab left to stage? (also fences LDS reuse)
-            if (!any) break;
-            HTN_ROUND(r1, oa1, ob1, k1, v1)
-            any = __syncthreads_or(v0 ? 1 : 0) != 0;
-        }
-#undef HTN_ROUND
-    } else {
-        // Cursor of this quad over the tile's flat slab sequence (quad q takes slabs q, q+4, q+8, ...).  The
-        // segment DESCRIPTOR of the slab after the one being fetched is loaded one round ahead, so the data loads
-        // of a round never wait for a descriptor (a cold 64-byte scalar load costs ~0.6 us on the critical path).
-        Cursor cur = {0, 0};
-        advance(cur, q, segs, T.seg_begin, n_gemm, presplit);
-        bool valid = cur.s < n_gemm;
-        htn_seg Sd = {};            // never read a descriptor that does not exist (a tile may own zero segments)
-        if (valid) Sd = segs[T.seg_begin + cur.s];
-        Slab regs;
-        load_slab(regs, bufs, T, Sd, cur, valid, tq);
-        Cursor nxt = cur;
-        bool nvalid = false;
-        if (valid) {
-            advance(nxt, NQ, segs, T.seg_begin, n_gemm, presplit);
-            nvalid = nxt.s < n_gemm;
-        }
-        htn_seg Sn = {};
-        if (nvalid) Sn = segs[T.seg_begin + nxt.s];
-        bool any = n_gemm > 0;
-        while (any) {
-            const int op_a = valid ? Sd.op_a : 0, op_b = valid ? Sd.op_b : 0;
-            const int kleft = valid ? Sd.k - cur.k0 : 0;
-            store_slab(regs, lds, op_a, op_b, tq);
-            __syncthreads();
-            const bool cur_valid = valid;
-            // the prefetched descriptor becomes current: issue the next slab's global loads before the MFMAs
-            cur = nxt;
-            valid = nvalid;
-            Sd = Sn;
-            load_slab(regs, bufs, T, Sd, cur, valid, tq);
-            nvalid = false;
-            if (valid) {
-                nxt = cur;
-                advance(nxt, NQ, segs, T.seg_begin, n_gemm, presplit);
-                nvalid = nxt.s < n_gemm;
+    // ---- K loop: group g takes slabs g, g + ngrp, ... of the tile's flat slab sequence.  GEMM_DEPTH register sets
+    // rotate: the loads of the next GEMM_DEPTH - 1 slabs are in flight while the current slab's 16 MFMAs issue (an
+    // operand fetch out of L2 / Infinity Cache takes 1.5-2 us, a slab's MFMAs 0.43 us) ----
+    if (n_gemm > 0) {
+        // The segment DESCRIPTOR of the slab after the one being fetched is read (from LDS) one step ahead (Sn).
+        Cursor cn = {0, 0};
+        advance(cn, grp, sg, n_gemm, presplit);
+        bool vn = cn.s < n_gemm;
+        htn_seg Sn = read_seg(s_desc, sg, vn ? cn.s : n_gemm - 1, n_staged);      // always a real descriptor: load_ops loads from it
+        Ops r[GEMM_DEPTH];
+#pragma unroll
+        for (int d = 0; d < GEMM_DEPTH; ++d) {
+            load_ops(r[d], bufs, Sn, cn, vn, arow, bcol, l4);
+            if (vn) {
+                advance(cn, ngrp, sg, n_gemm, presplit);
+                vn = cn.s < n_gemm;
+                if (vn) Sn = read_seg(s_desc, sg, cn.s, n_staged);
             }
-            if (cur_valid) {
-                const int ksteps = kleft >= KB ? KB / 4 : (kleft + 3) >> 2;
-                for (int ks = 0; ks < ksteps; ++ks) {
-                    const int kk = ks * 4 + l4;
-                    const double b_re = lds[2 * SLAB + LDS_AT(kk, wc * 16 + l15)];   // Aop[i][k] = B[k][c0+i]
-                    const double b_im = lds[3 * SLAB + LDS_AT(kk, wc * 16 + l15)];
-                    const double a_re = lds[0 * SLAB + LDS_AT(kk, wr * 16 + l15)];   // Bop[k][j] = A[r0+j][k]
-                    const double a_im = lds[1 * SLAB + LDS_AT(kk, wr * 16 + l15)];
-                    acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_re, acc_re, 0, 0, 0);
-                    acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-b_im, a_im, acc_re, 0, 0, 0);
-                    acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_re, a_im, acc_im, 0, 0, 0);
-                    acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(b_im, a_re, acc_im, 0, 0, 0);
+        }
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int d = 0; d < GEMM_DEPTH; ++d) {
+                if (r[d].ksteps == 0) {              // past the last slab of this group (wave-uniform)
+                    more = false;
+                    break;
+                }
+                mfma_ops(r[d], acc_re, acc_im, l4);
+                load_ops(r[d], bufs, Sn, cn, vn, arow, bcol, l4);
+                if (vn) {
+                    advance(cn, ngrp, sg, n_gemm, presplit);
+                    vn = cn.s < n_gemm;
+                    if (vn) Sn = read_seg(s_desc, sg, cn.s, n_staged);
                 }
             }
-            // descriptor of the slab after next: issued AFTER the MFMA phase -- scalar loads share lgkmcnt with the LDS
-            // reads of the MFMA operands, so an earlier issue would stall the first MFMA on this cold load; here its
-            // latency hides behind the barrier and the next round's LDS staging
-            if (nvalid) Sn = segs[T.seg_begin + nxt.s];
-            any = __syncthreads_or(valid ? 1 : 0) != 0;     // also fences LDS reuse
         }
     }
-    // ---- COPY segments: C += alpha * X tile, spread over the quads (each adds into its partial) ----
-    // this lane's outputs are C[r0 + l15][c0 + l4 + 4 r], r = 0..3
-    const int orow = wr * 16 + l15;
-    for (int s = n_gemm + q; s < T.seg_count; s += NQ) {
-        const htn_seg S = segs[T.seg_begin + s];
+#ifdef HTN_GEMM_PROF
+    const long long prof_t1 = wall_clock64();
+    const long long prof_c1 = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    // ---- COPY segments: C += alpha * X tile, spread over the K groups (each adds into its partial) ----
+    for (int s = n_gemm + grp; s < T.seg_count; s += ngrp) {
+        const htn_seg S = sg[s];
         const double2* __restrict__ Bp = bufs.p[S.buf_b] + S.b_off;
         if (orow < T.m) {
 #pragma unroll
@@ -292,26 +242,25 @@ __global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, cons
             }
         }
     }
-    // ---- reduce the 4 partial accumulators through LDS (fixed order => deterministic) ----
-    __syncthreads();
-    double* red = lds_all;                      // [3][256][8] doubles = 48 KiB
-    if (q > 0) {
-        double* dst = red + ((q - 1) * 256 + tq) * 8;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dst[r] = acc_re[r];
-            dst[4 + r] = acc_im[r];
-        }
-    }
-    __syncthreads();
-    if (q == 0) {
-#pragma unroll
-        for (int p = 0; p < NQ - 1; ++p) {
-            const double* src = red + (p * 256 + tq) * 8;
+    // ---- reduce the partial accumulators of the K groups through LDS (fixed order => deterministic) ----
+    if (ngrp > 1) {
+        if (grp > 0) {
+            double* dst = red + (((grp - 1) * nquad + quad) * 64 + lane) * 8;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                acc_re[r] += src[r];
-                acc_im[r] += src[4 + r];
+                dst[r] = acc_re[r];
+                dst[4 + r] = acc_im[r];
+            }
+        }
+        __syncthreads();
+        if (grp == 0) {
+            for (int p = 0; p < ngrp - 1; ++p) {
+                const double* src = red + ((p * nquad + quad) * 64 + lane) * 8;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc_re[r] += src[r];
+                    acc_im[r] += src[4 + r];
+                }
             }
         }
     }
@@ -322,18 +271,20 @@ __global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, cons
     // whatever the arrival order) and writes the tile.  In-launch hand-off across CUs / XCDs: plain slab stores,
     // vmcnt drain, workgroup barrier, ONE agent-scope release + relaxed agent ticket add; the reducer: ONE agent-scope
     // acquire, then plain loads (cdna_hip_programming.md, "in-launch split-K reduction").  The ticket is reset by the
-    // reducer: it is zero before every launch (zero-initialised once by the owner of the workspace). ----
+    // reducer: it is zero before every launch (zero-initialised once by the owner of the workspace).  Slab layout:
+    // [quadrant wr * 2 + wc][lane][reg] -- every part of a tile has the same quadrants. ----
     if (T.nparts > 1) {
         double2* __restrict__ ws = bufs.p[HTN_BUF_WS];
         int* __restrict__ tickets = (int*)ws;
+        const int sidx = ((wr * 2 + wc) * 64 + lane) * 4;
         double2* __restrict__ slab = ws + HTN_WS_TICKET_ELEMS + (int64_t)(T.ws_slot + T.part) * (HTN_TILE * HTN_TILE);
-        if (q == 0) {
+        if (grp == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) slab[tq * 4 + r] = make_double2(acc_re[r], acc_im[r]);
+            for (int r = 0; r < 4; ++r) slab[sidx + r] = make_double2(acc_re[r], acc_im[r]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int* flag = (int*)lds_all;               // (the LDS planes are dead now; ONE __shared__ object in this kernel)
+        int* flag = (int*)red;                   // (the partials are dead now)
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -347,8 +298,8 @@ __global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, cons
             __hip_atomic_store(&tickets[T.ticket], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (q == 0) {
-            const double2* __restrict__ s0 = ws + HTN_WS_TICKET_ELEMS + (int64_t)T.ws_slot * (HTN_TILE * HTN_TILE) + tq * 4;
+        if (grp == 0) {
+            const double2* __restrict__ s0 = ws + HTN_WS_TICKET_ELEMS + (int64_t)T.ws_slot * (HTN_TILE * HTN_TILE) + sidx;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc_re[r] = acc_im[r] = 0.0;
             for (int p = 0; p < T.nparts; ++p) {
@@ -361,7 +312,7 @@ __global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, cons
             }
         }
     }
-    if (q == 0 && orow < T.m) {
+    if (grp == 0 && orow < T.m) {
         double2* __restrict__ Cp = bufs.p[T.buf_c] + T.c_off;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -371,6 +322,20 @@ __global__ __launch_bounds__(256 * NQ) void k_grouped_gemm_z(BufTable bufs, cons
                     make_double2(acc_re[r], acc_im[r]);
         }
     }
+#ifdef HTN_GEMM_PROF
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        long long* o = g_gemm_prof + 6 * (size_t)blockIdx.x;
+        o[4] = prof_c1 - prof_c0;
+        o[5] = n_gemm * 256 + nquad;
+        o[0] = prof_t0;
+        o[1] = prof_t1;
+        o[2] = wall_clock64();
+        o[3] = ((long long)(xcc & 0xf) << 32) | hwid;
+    }
+#endif
 }
 
 extern "C" int htn_grouped_gemm_z(const void* const* bufs_host, const htn_tile* tiles, int32_t n_tiles,
@@ -378,7 +343,7 @@ extern "C" int htn_grouped_gemm_z(const void* const* bufs_host, const htn_tile* 
     if (n_tiles <= 0) return 0;
     BufTable bt;
     for (int i = 0; i < HTN_MAX_BUFS; ++i) bt.p[i] = (double2*)bufs_host[i];
-    hipLaunchKernelGGL(k_grouped_gemm_z, dim3(n_tiles), dim3(256 * NQ), 0, (hipStream_t)stream, bt, tiles, segs);
+    hipLaunchKernelGGL(k_grouped_gemm_z, dim3(n_tiles), dim3(64 * GEMM_WAVES), 0, (hipStream_t)stream, bt, tiles, segs);
     HIP_TRY(hipGetLastError());
     return 0;
 }

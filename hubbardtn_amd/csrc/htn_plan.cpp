@@ -496,40 +496,74 @@ inline Key tkey(Sec a, int s1, Sec c, int s2, Sec b) { return mk(a.N, a.j, s1, c
 
 }  // namespace
 
-// ---- load balance of a launch: split-K across workgroups + XCD-aware order ---------------------------------------------
+// ---- load balance of a launch: split-K across workgroups + placement-aware order ----------------------------------------
+// Cost model of k_grouped_gemm_z (htn_gemm.hip): a tile is one 4-wave workgroup, one wave per SIMD; a tile with q = 1, 2
+// or 4 quadrants splits its S slabs 4 / q ways, so it keeps each SIMD of its CU busy for ceil(S q / 4) slab units (16 MFMAs,
+// ~0.6 us at the clock the chip holds under MFMA load).  A launch is bound by the most loaded CU, and where a workgroup lands
+// is deterministic while every CU still has a free slot (measured, tools/gemm_prof.py): workgroup p goes to XCD p % 8 and,
+// inside the XCD, to its CUs in a fixed rotation -- workgroup 256 + j lands on the CU of workgroup j.  Hence:
+//   1. tiles whose load exceeds the cap (a fraction of the balanced share of a CU) are cut: first spatially into their
+//      quadrants, then -- if one quadrant is still too long -- into parts along K (split-K across workgroups: the parts run
+//      on different CUs and meet through the workspace, see the kernel; that hand-off costs several us);
+//   2. the parts are dealt in LAYERS of n_cus: layer 0 = the n_cus longest, one per CU; every later layer gives each CU
+//      one more part, longest part to the least loaded CU -- preferably a CU of the XCD where the part's output strip
+//      already lives (operands then come out of that XCD's L2); GEMM_LAYERS layers are co-resident (occupancy);
+//   3. whatever does not fit those layers follows longest first: it is dispatched dynamically as slots free up.
 int balance_tiles(Tasks& t, int n_cus) {
     const int nt = t.ntiles;
     if (nt <= 0) return 0;
-    auto slabs = [](const htn_tile& T) { return std::max(0, T.seg_count - T.pad[0]); };
-    int64_t total = 0;
-    for (int i = 0; i < nt; ++i) total += slabs(t.tiles[i]);
-    // a workgroup's NQ wave-quads take NQ slabs per round: parts are sized in rounds.  cap = the balanced share of one
-    // workgroup slot (2 co-resident workgroups per CU at NQ = 2)
-    const int NQ = HTN_GEMM_QUADS;
-    const int64_t slots = (int64_t)n_cus * (4 / NQ);
-    int cap_rounds = (int)((total + NQ * slots - 1) / (NQ * slots));
-    cap_rounds = std::max(cap_rounds, 12 / NQ);        // below ~12 slabs the hand-off costs more than it saves
-    // tuning knobs for measurements (tools/apply_bench.py): rounds per part, XCD dealing on / off
-    static const int env_cap = getenv("HTN_GEMM_CAP_ROUNDS") ? atoi(getenv("HTN_GEMM_CAP_ROUNDS")) : 0;
+    static const int env_cap = getenv("HTN_GEMM_CAP") ? atoi(getenv("HTN_GEMM_CAP")) : 0;
+    static const int env_capk = getenv("HTN_GEMM_CAPK") ? atoi(getenv("HTN_GEMM_CAPK")) : 0;
     static const int env_xcd = getenv("HTN_GEMM_XCD") ? atoi(getenv("HTN_GEMM_XCD")) : 1;
-    if (env_cap > 0) cap_rounds = env_cap;
-    std::vector<htn_tile> out;
-    out.reserve((size_t)nt + 64);
-    int ws = 0, tickets = 0;
+    static const int env_layers = getenv("HTN_GEMM_LAYERS") ? atoi(getenv("HTN_GEMM_LAYERS")) : 3;
+    auto slabs = [](const htn_tile& T) { return std::max(0, T.seg_count - T.pad[0]); };
+    auto ways = [](const htn_tile& T) { return 4 / ((T.m > 16 ? 2 : 1) * (T.n > 16 ? 2 : 1)); };
+    auto load = [&](const htn_tile& T) { const int g = ways(T); return (slabs(T) + g - 1) / g + 1; };   // + 1: prologue / epilogue
+    int64_t total = 0;
+    for (int i = 0; i < nt; ++i) total += load(t.tiles[i]);
+    const int64_t share = (total + n_cus - 1) / n_cus;        // balanced load of one CU
+    // spatial cut: no hand-off, so a small fraction of the share -- but only while the launch has fewer workgroups than the
+    // CUs can hold (4 per CU): beyond that more workgroups add prologues and operand re-reads, not parallelism
+    int cap = nt >= 4 * n_cus ? (1 << 30) : std::max((int)(2 * share / 5), 4);
+    int cap_k = std::max((int)share, 12);                       // K cut: the hand-off costs several us
+    if (env_cap > 0) cap = env_cap;
+    if (env_capk > 0) cap_k = env_capk;
+    // 1a. spatial cut: a tile of 2 or 4 quadrants whose load exceeds the cap becomes 2 or 4 one-quadrant tiles sharing its
+    //     segment list (same MFMA work, spread over 2 or 4 CUs; every one of them splits K four ways; nothing to reduce)
+    std::vector<htn_tile> src;
+    src.reserve((size_t)nt * 2);
     for (int i = 0; i < nt; ++i) {
-        htn_tile T = t.tiles[i];
+        const htn_tile& T = t.tiles[i];
+        const int g = ways(T);
+        if (g == 4 || (slabs(T) + g - 1) / g <= cap) {
+            src.push_back(T);
+            continue;
+        }
+        for (int r0 = 0; r0 < T.m; r0 += 16)
+            for (int c0 = 0; c0 < T.n; c0 += 16) {
+                htn_tile Q = T;
+                Q.row0 = T.row0 + r0, Q.col0 = T.col0 + c0;
+                Q.m = std::min(16, T.m - r0), Q.n = std::min(16, T.n - c0);
+                src.push_back(Q);
+            }
+    }
+    std::vector<htn_tile> out;
+    out.reserve(src.size() + 64);
+    int ws = 0, tickets = 0;
+    for (size_t i = 0; i < src.size(); ++i) {
+        htn_tile T = src[i];
         T.part = 0, T.nparts = 1, T.ws_slot = 0, T.ticket = 0;
-        const int S = slabs(T), rounds = (S + NQ - 1) / NQ;
-        int np = rounds > cap_rounds + 1 ? (rounds + cap_rounds - 1) / cap_rounds : 1;
+        const int S = slabs(T), g = ways(T), ld = (S + g - 1) / g;
+        const int np = ld > cap_k + cap_k / 4 ? (ld + cap_k - 1) / cap_k : 1;
         if (np <= 1 || T.pad[1] == 0 || tickets >= HTN_WS_TICKET_ELEMS * 4 - 1) {
             out.push_back(T);
             continue;
         }
-        const int base = rounds / np, extra = rounds % np;       // rounds per part: the first `extra` parts take one more
+        const int base = ld / np, extra = ld % np;         // slab units per part: the first `extra` parts take one more
         int pos = 0;
         for (int p = 0; p < np; ++p) {
-            const int r = base + (p < extra ? 1 : 0);
-            const int cnt = std::min(NQ * r, S - pos);
+            const int u = base + (p < extra ? 1 : 0);
+            const int cnt = p == np - 1 ? S - pos : std::min(g * u, S - pos);
             htn_tile P = T;
             P.seg_begin = T.seg_begin + pos;
             P.seg_count = cnt + (p == np - 1 ? T.pad[0] : 0);     // COPY segments ride with the last part
@@ -541,43 +575,70 @@ int balance_tiles(Tasks& t, int n_cus) {
         ws += np;
         ++tickets;
     }
-    // longest first (LPT), then dealt over 8 XCD queues: a tile goes where its (output block, row strip) already lives,
-    // a new strip to the least loaded queue; position p of the final list runs on XCD p % 8 under round-robin placement
-    std::vector<int> order(out.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    auto cost = [&](const htn_tile& T) { return (int64_t)slabs(T) + 5; };
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(out[a]) > cost(out[b]); });
-    const int NX = env_xcd ? 8 : 1;
-    std::vector<std::vector<int>> q(NX);
-    int64_t load[8] = {0};
+    const int n = (int)out.size();
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load(out[a]) > load(out[b]); });
+    const int NX = (env_xcd && n_cus % 8 == 0) ? 8 : 1, per = n_cus / NX;       // CU (x, k) <-> launch position 8 k + x of a layer
+    const int n_layers = std::min(std::max(env_layers, 1), (n + n_cus - 1) / n_cus);
+    std::vector<int64_t> cu_load((size_t)n_cus, 0), x_load(NX, 0);
+    std::vector<std::vector<int>> cu_tiles((size_t)n_cus);
     std::unordered_map<Key, int, KeyHash> home;
-    for (int i : order) {
-        const htn_tile& T = out[i];
-        const Key k = mk(T.buf_c, (int32_t)(T.c_off & 0x7fffffff), (int32_t)(T.c_off >> 31), T.row0);
-        auto it = home.find(k);
-        int x;
-        if (it == home.end()) {
-            x = 0;
-            for (int j = 1; j < NX; ++j)
-                if (load[j] < load[x]) x = j;
-            home[k] = x;
-        } else
-            x = it->second;
-        // a strip much heavier than a fair share would serialise its XCD: overflow goes to the least loaded queue
-        if (load[x] > (total + 5 * (int64_t)out.size()) / NX) {
-            int y = 0;
-            for (int j = 1; j < NX; ++j)
-                if (load[j] < load[y]) y = j;
-            x = y;
+    int next = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int cnt = std::min(n_cus, n - next);
+        // the XCD of every part of this layer: its strip's home if that XCD still has room in the layer
+        std::vector<int> room(NX, per), xs(cnt);
+        if (cnt < n_cus)            // last, partial layer: launch positions are filled in order, XCD x gets ceil / floor
+            for (int x = 0; x < NX; ++x) room[x] = cnt / NX + (x < cnt % NX ? 1 : 0);
+        for (int j = 0; j < cnt; ++j) {
+            const htn_tile& T = out[order[next + j]];
+            const Key k = mk(T.buf_c, (int32_t)(T.c_off & 0x7fffffff), (int32_t)(T.c_off >> 31), T.row0);
+            auto it = home.find(k);
+            int x = it == home.end() ? -1 : it->second;
+            if (x < 0 || room[x] == 0) {
+                int y = -1;
+                for (int c = 0; c < NX; ++c)
+                    if (room[c] > 0 && (y < 0 || x_load[c] < x_load[y])) y = c;
+                if (x < 0) home[k] = y;
+                x = y;
+            }
+            --room[x];
+            xs[j] = x;
+            x_load[x] += load(T);
         }
-        q[x].push_back(i);
-        load[x] += cost(T);
+        // inside the XCD: longest part of the layer to the least loaded CU that has no part of this layer yet
+        std::vector<char> taken((size_t)n_cus, 0);
+        for (int j = 0; j < cnt; ++j) {
+            const int i = order[next + j], x = xs[j];
+            int best = -1;
+            for (int k = 0; k < per; ++k) {
+                const int c = k * NX + x;
+                if (!taken[c] && (best < 0 || cu_load[c] < cu_load[best])) best = c;
+            }
+            taken[best] = 1;
+            cu_tiles[best].push_back(i);
+            cu_load[best] += load(out[i]);
+        }
+        next += cnt;
+    }
+    // launch order: CUs that take part in the last (possibly partial) layer come first inside their XCD -- the rotation of
+    // an XCD restarts at its first CU with every layer
+    std::vector<std::vector<int>> cus(NX);
+    for (int x = 0; x < NX; ++x) {
+        for (int k = 0; k < per; ++k) cus[x].push_back(k * NX + x);
+        std::stable_sort(cus[x].begin(), cus[x].end(),
+                         [&](int a, int b) { return cu_tiles[a].size() > cu_tiles[b].size(); });
     }
     std::vector<htn_tile> fin;
-    fin.reserve(out.size());
-    for (size_t r = 0; fin.size() < out.size(); ++r)
-        for (int x = 0; x < NX; ++x)
-            if (r < q[x].size()) fin.push_back(out[q[x][r]]);
+    fin.reserve((size_t)n);
+    for (int l = 0; l < n_layers; ++l)
+        for (int k = 0; k < per; ++k)
+            for (int x = 0; x < NX; ++x) {
+                const int c = cus[x][k];
+                if ((int)cu_tiles[c].size() > l) fin.push_back(out[cu_tiles[c][l]]);
+            }
+    for (int j = next; j < n; ++j) fin.push_back(out[order[j]]);
     t.tiles.swap(fin);
     t.ntiles = (int32_t)t.tiles.size();
     return ws;

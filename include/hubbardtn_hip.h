@@ -29,9 +29,8 @@ extern "C" {
 #define HTN_ABI_VERSION 2
 #define HTN_MAX_BUFS 8
 #define HTN_TILE 32              /* output tile edge of the grouped GEMM */
-#define HTN_GEMM_QUADS 4         /* wave-quads per workgroup of the grouped GEMM = K slabs (16 deep) a workgroup retires per
-                                    round (1024 threads, 96 KiB LDS, one workgroup per CU).  Measured alternative: 2 quads
-                                    (two co-resident 512-thread workgroups) is slower, 50 vs 38 us per chi=1024 apply */
+/* grouped GEMM: one 4-wave workgroup per tile, several co-resident per CU; a tile of q = 1, 2 or 4 quadrants (16 x 16)
+ * splits its K slabs 4 / q ways over its waves (htn_gemm.hip). */
 
 /* operand ops */
 #define HTN_OP_N 0               /* as stored                        */
