@@ -64,7 +64,8 @@ struct Ops {
     double c1, c2, c3, c4;    // alpha * op(a):  re = c1 a.x + c2 a.y,  im = c3 a.y + c4 a.x
     int ksteps;               // 0: past the last slab
     int kleft;                // k extent of the slab (1..16): lanes with 4 ks + l4 >= kleft contribute zero
-    bool conj_b;
+    unsigned bflip;           // 0x80000000 if op(B) conjugates (xor-ed into the sign of b.y)
+    bool real_alpha;          // alpha_im == 0: two multiplications instead of four per element
 };
 
 __device__ __forceinline__ double sflip(double x, bool neg) {
@@ -85,7 +86,8 @@ __device__ __forceinline__ void load_ops(Ops& r, const BufTable& bufs, const htn
     r.kleft = kleft;
     r.ksteps = valid ? (kleft + 3) >> 2 : 0;
     const bool an = S.op_a == HTN_OP_N, bn = S.op_b == HTN_OP_N, ca = S.op_a == HTN_OP_C;
-    r.conj_b = S.op_b == HTN_OP_C;
+    r.bflip = S.op_b == HTN_OP_C ? 0x80000000u : 0u;
+    r.real_alpha = ((unsigned long long)__double_as_longlong(S.alpha_im) << 1) == 0ull;      // (integer test: stays on the SALU)
     r.c1 = S.alpha_re;                               // (sign flips on the bit pattern: SALU, the values stay in SGPRs)
     r.c2 = sflip(S.alpha_im, !ca);
     r.c3 = sflip(S.alpha_re, ca);
@@ -94,12 +96,13 @@ __device__ __forceinline__ void load_ops(Ops& r, const BufTable& bufs, const htn
     const int b_sc = bn ? S.ldb : 1, b_sk = bn ? 1 : S.ldb;           //                  op(B): column, k
     const char* __restrict__ Ab = (const char*)(bufs.p[S.buf_a] + S.a_off + (int64_t)k0 * a_sk);
     const char* __restrict__ Bb = (const char*)(bufs.p[S.buf_b] + S.b_off + (int64_t)k0 * b_sk);
-    const unsigned ar = (unsigned)(arow * a_sr), bc = (unsigned)(bcol * b_sc);
+    // (24-bit multiplies: v_mul_lo_u32 is quarter rate; rows, strides and k are far below 2^24, products below 2^31)
+    const unsigned ar = __umul24((unsigned)arow, (unsigned)a_sr), bc = __umul24((unsigned)bcol, (unsigned)b_sc);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const int kl = min(4 * ks + l4, kleft - 1);
-        r.a[ks] = *(const double2*)(Ab + (size_t)((ar + (unsigned)(kl * a_sk)) << 4));
-        r.b[ks] = *(const double2*)(Bb + (size_t)((bc + (unsigned)(kl * b_sk)) << 4));
+        const unsigned kl = (unsigned)min(4 * ks + l4, kleft - 1);
+        r.a[ks] = *(const double2*)(Ab + (size_t)((ar + __umul24(kl, (unsigned)a_sk)) << 4));
+        r.b[ks] = *(const double2*)(Bb + (size_t)((bc + __umul24(kl, (unsigned)b_sk)) << 4));
     }
 }
 
@@ -107,18 +110,30 @@ __device__ __forceinline__ void mfma_ops(const Ops& r, d4& acc_re, d4& acc_im, i
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         if (ks < r.ksteps) {                         // wave-uniform
-            const bool live = 4 * ks + l4 < r.kleft;
-            const double ax = live ? r.a[ks].x : 0.0, ay = live ? r.a[ks].y : 0.0;
-            const double a_re = fma(r.c1, ax, r.c2 * ay), a_im = fma(r.c3, ay, r.c4 * ax);
-            const double bx = r.b[ks].x, by = r.conj_b ? -r.b[ks].y : r.b[ks].y;
+            double ax = r.a[ks].x, ay = r.a[ks].y;
+            if (4 * ks + 4 > r.kleft) {              // the slab's last, partial k step (wave-uniform): lanes beyond k give 0
+                const bool live = 4 * ks + l4 < r.kleft;
+                ax = live ? ax : 0.0;
+                ay = live ? ay : 0.0;
+            }
+            double a_re, a_im;
+            if (r.real_alpha) {                      // wave-uniform
+                a_re = r.c1 * ax;
+                a_im = r.c3 * ay;
+            } else {
+                a_re = fma(r.c1, ax, r.c2 * ay);
+                a_im = fma(r.c3, ay, r.c4 * ax);
+            }
+            const double bx = r.b[ks].x;
+            const double by = __hiloint2double(__double2hiint(r.b[ks].y) ^ (int)r.bflip, __double2loint(r.b[ks].y));
+            // re / im alternate: an MFMA never depends on the one issued just before it
             acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(bx, a_re, acc_re, 0, 0, 0);
-            acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-by, a_im, acc_re, 0, 0, 0);
             acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(bx, a_im, acc_im, 0, 0, 0);
+            acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(-by, a_im, acc_re, 0, 0, 0);
             acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(by, a_re, acc_im, 0, 0, 0);
         }
     }
 }
-
 
 // Segment descriptors are staged ONCE per workgroup in LDS (coalesced vector loads) and read from there per slab: a scalar
 // load of a cold 64-byte descriptor costs ~0.6 us and, SMEM returning out of order, cannot be kept more than one deep --

@@ -507,15 +507,16 @@ inline Key tkey(Sec a, int s1, Sec c, int s2, Sec b) { return mk(a.N, a.j, s1, c
 //      on different CUs and meet through the workspace, see the kernel; that hand-off costs several us);
 //   2. the parts are dealt in LAYERS of n_cus: layer 0 = the n_cus longest, one per CU; every later layer gives each CU
 //      one more part, longest part to the least loaded CU -- preferably a CU of the XCD where the part's output strip
-//      already lives (operands then come out of that XCD's L2); GEMM_LAYERS layers are co-resident (occupancy);
+//      already lives (operands then come out of that XCD's L2); GEMM_RESIDENT layers are co-resident (occupancy);
 //   3. whatever does not fit those layers follows longest first: it is dispatched dynamically as slots free up.
+#define GEMM_RESIDENT 4      // workgroups of k_grouped_gemm_z co-resident per CU (its launch bounds: 4 waves per SIMD)
 int balance_tiles(Tasks& t, int n_cus) {
     const int nt = t.ntiles;
     if (nt <= 0) return 0;
     static const int env_cap = getenv("HTN_GEMM_CAP") ? atoi(getenv("HTN_GEMM_CAP")) : 0;
     static const int env_capk = getenv("HTN_GEMM_CAPK") ? atoi(getenv("HTN_GEMM_CAPK")) : 0;
     static const int env_xcd = getenv("HTN_GEMM_XCD") ? atoi(getenv("HTN_GEMM_XCD")) : 1;
-    static const int env_layers = getenv("HTN_GEMM_LAYERS") ? atoi(getenv("HTN_GEMM_LAYERS")) : 3;
+    static const int env_layers = getenv("HTN_GEMM_LAYERS") ? atoi(getenv("HTN_GEMM_LAYERS")) : GEMM_RESIDENT;
     auto slabs = [](const htn_tile& T) { return std::max(0, T.seg_count - T.pad[0]); };
     auto ways = [](const htn_tile& T) { return 4 / ((T.m > 16 ? 2 : 1) * (T.n > 16 ? 2 : 1)); };
     auto load = [&](const htn_tile& T) { const int g = ways(T); return (slabs(T) + g - 1) / g + 1; };   // + 1: prologue / epilogue
@@ -524,7 +525,8 @@ int balance_tiles(Tasks& t, int n_cus) {
     const int64_t share = (total + n_cus - 1) / n_cus;        // balanced load of one CU
     // spatial cut: no hand-off, so a small fraction of the share -- but only while the launch has fewer workgroups than the
     // CUs can hold (4 per CU): beyond that more workgroups add prologues and operand re-reads, not parallelism
-    int cap = nt >= 4 * n_cus ? (1 << 30) : std::max((int)(2 * share / 5), 4);
+    const int slots = GEMM_RESIDENT * n_cus;                   // workgroups the chip holds at once
+    int cap = nt >= slots ? (1 << 30) : std::max((int)(2 * share / 5), 4);
     int cap_k = std::max((int)share, 12);                       // K cut: the hand-off costs several us
     if (env_cap > 0) cap = env_cap;
     if (env_capk > 0) cap_k = env_capk;
