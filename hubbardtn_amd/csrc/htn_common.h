@@ -27,6 +27,26 @@ static inline int htn_fail_msg(const char* what) {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// ---- host waits on the latency-critical path: poll, do not sleep ------------------------------------------------------
+// hipStreamSynchronize / hipEventSynchronize put the calling thread to sleep and wake it by interrupt (tens of us per wait,
+// several waits per bond update); the sweep driver's waits are short, so it polls instead.
+static inline hipError_t htn_event_spin(hipEvent_t ev) {
+    hipError_t e;
+    while ((e = hipEventQuery(ev)) == hipErrorNotReady) __builtin_ia32_pause();
+    return e;
+}
+static inline hipError_t htn_stream_spin(hipStream_t st) {
+    static thread_local hipEvent_t evs[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipStreamSynchronize(st);
+    if (!evs[dev] && (e = hipEventCreateWithFlags(&evs[dev], hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventRecord(evs[dev], st)) != hipSuccess) return e;
+    return htn_event_spin(evs[dev]);
+}
+
+
 // ---- cross-lane sums -------------------------------------------------------------------------------
 // Within a row of 16 lanes the butterfly runs on DPP (pure VALU, no LDS crossbar round trip):
 // quad_perm xor-1, quad_perm xor-2, row_half_mirror, row_mirror.  Across rows ds_bpermute (__shfl_xor).

@@ -520,7 +520,7 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
             if (wait_step(j)) return 1;
             if (timed_step[j]) {
                 float ms = 0.f;
-                HIP_TRY(hipEventSynchronize(ev_mv1[j]));
+                HIP_TRY(htn_event_spin(ev_mv1[j]));
                 HIP_TRY(hipEventElapsedTime(&ms, ev_mv0[j], ev_mv1[j]));
                 mv_ms += ms;
                 ++n_timed;
@@ -535,7 +535,7 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
             if (res < tol || beta < 1e-14 * std::max(amax, 1e-300) || j == kd - 1) break;
             betas.push_back(beta);
         }
-        HIP_TRY(hipStreamSynchronize(st));       // drain the speculative step before rows are reused
+        HIP_TRY(htn_stream_spin(st));       // drain the speculative step before rows are reused
         // x = sum_i y_i V_i  -> scratch row kd+1, normalised into row 0
         const int k = (int)y.size();
         for (int i = 0; i < k; ++i) h_y[i] = make_double2(y[i], 0.0);
@@ -546,7 +546,7 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         hipLaunchKernelGGL(k_norm_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, xrow, n, norm_partial);
         hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, V, xrow, norm_partial, n,
                            (double*)nullptr);
-        HIP_TRY(hipStreamSynchronize(st));      // h_y is reused by the next restart / call
+        HIP_TRY(htn_stream_spin(st));      // h_y is reused by the next restart / call
         if (res < tol || beta < 1e-14 * std::max(amax, 1e-300)) break;
     }
     HIP_TRY(hipGetLastError());

@@ -1372,7 +1372,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     for (int li = 0; li < nl; ++li) n_eff[li] = desc_host[large[li]].n;
     if (cut2 > 0.0) {        // the tournament is sized by the ranks the QR found: wait for them (one sync per call)
         HIP_TRY(hipEventRecord(g_js.ev_sweep[0], st));
-        HIP_TRY(hipEventSynchronize(g_js.ev_sweep[0]));
+        HIP_TRY(htn_event_spin(g_js.ev_sweep[0]));
         for (int li = 0; li < nl; ++li) n_eff[li] = std::min(n_eff[li], (int)h_rank[li]);
     }
     build_rounds(n_eff.data());
@@ -1418,7 +1418,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
             HIP_TRY(enqueue_sweep(sweep + 1));
             ++enq;
         }
-        HIP_TRY(hipEventSynchronize(g_js.ev_sweep[sweep & 1]));
+        HIP_TRY(htn_event_spin(g_js.ev_sweep[sweep & 1]));
         used = sweep + 1;
         if (h_active[sweep] == 0) break;
         if (sweep + 1 < max_sweeps && enq == sweep + 1) {
@@ -1431,7 +1431,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     hipLaunchKernelGGL(k_jacobi_finish, dim3(nl), dim3(JAC_THREADS), 0, st, (double2*)G, (const double2*)Vj, S, desc,
                        d_ids, d_perm, d_sw, d_done, info_dev);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));      // the pinned staging block is reused by the next call
+    HIP_TRY(htn_stream_spin(st));      // the pinned staging block is reused by the next call
     return 0;
 }
 

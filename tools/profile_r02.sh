@@ -1,10 +1,10 @@
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r02b -o r02b --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/r02b_bench_under_rocprof.json 2> $R/gpurun_out/r02b.err
-KT=$(find $R/gpurun_out/prof_r02b -name "*kernel_trace.csv")
-python $R/tools/trace_tail.py $KT 0.12 > $R/gpurun_out/r02b_trace_tail_steady_state.txt
-python $R/tools/bond_timeline.py $KT 40 > $R/gpurun_out/r02b_bond_timeline.txt
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r02c -o r02c --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/r02c_bench_under_rocprof.json 2> $R/gpurun_out/r02c.err
+KT=$(find $R/gpurun_out/prof_r02c -name "*kernel_trace.csv")
+python $R/tools/trace_tail.py $KT 0.12 > $R/gpurun_out/r02c_trace_tail_steady_state.txt
+python $R/tools/bond_timeline.py $KT 40 > $R/gpurun_out/r02c_bond_timeline.txt
 rm -f $KT
 echo trace done
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_grouped_gemm_z" -d $R/gpurun_out/pmc_r02_fetch -o f --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/pmc1.err
