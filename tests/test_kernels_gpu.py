@@ -56,6 +56,65 @@ def test_grouped_gemm_matches_numpy(hip_ops, seed, nblocks, maxdim, maxk):
     got = hip_ops.to_host(out)
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() <= 1e-12 * scale      # f64 MFMA, tolerance = accumulation order only
+    # the same list through the balancing pass: tiles cut into their quadrants, layered launch order
+    dev = hip_ops.upload_tasks(tasks, balance=True)
+    out2 = hip_ops.zeros_z(out_size)
+    hip_ops.grouped_gemm([d0, out2, d2] + [None] * 5, dev)
+    assert np.abs(hip_ops.to_host(out2) - ref).max() <= 1e-12 * scale
+    if maxdim > 32 and maxk > 80:
+        assert dev[1] > tasks.ntiles                     # some multi-quadrant tile was long enough to be cut
+
+
+def test_grouped_gemm_segments_longer_than_one_slab_and_every_quadrant_shape(hip_ops):
+    """the kernel-level ABI also takes segments whose k exceeds one 16-deep slab (htn_tile.pad[1] = 0: the waves walk
+    (segment, k offset) cursors) -- the planner never emits them, so they are built by hand here; block extents are chosen so
+    that the tiles cover every quadrant shape of the kernel (one, two side by side, two stacked, four; 1-, 15-, 16-, 17-wide
+    edges), with all op combinations, k not a multiple of 4 or 16, a COPY segment, and both with and without the library's
+    balancing pass"""
+    import ref_planner as pl
+    rng = np.random.default_rng(11)
+    nel = 300_000
+    shapes = [(1, 1), (15, 33), (16, 16), (17, 5), (32, 32), (40, 50), (31, 64), (64, 17), (3, 48)]
+    seg_rows, blk = [], []
+    pos = out_off = 0
+    for bi, (m, n) in enumerate(shapes):
+        ld = m + bi % 3
+        cnt = 0
+        for (k, op_a, op_b) in [(37, 0, 0), (100, 1, 2), (5, 2, 1), (16, 0, 1), (61, 2, 0)][:2 + bi % 4]:
+            lda = (m if op_a == abi.OP_N else k) + 1
+            ldb = (k if op_b == abi.OP_N else n) + 2
+            sa, sb = lda * (k if op_a == abi.OP_N else m), ldb * (n if op_b == abi.OP_N else k)
+            al = complex(rng.standard_normal(), rng.standard_normal() if (bi + cnt) % 2 else 0.0)
+            seg_rows.append((int(rng.integers(0, nel - sa - 1)), int(rng.integers(0, nel - sb - 1)), 0, 2, lda, ldb, k, op_a, op_b,
+                             abi.SEG_GEMM, al.real, al.imag))
+            cnt += 1
+        ncopy = 0
+        if bi % 2:
+            seg_rows.append((0, int(rng.integers(0, nel - (m + 3) * n - 1)), 0, 2, 0, m + 3, 0, 0, 0, abi.SEG_COPY, 0.7, -0.2))
+            cnt, ncopy = cnt + 1, 1
+        blk.append((out_off, ld, m, n, pos, cnt, ncopy))
+        pos += cnt
+        out_off += ld * n
+    segs = np.array(seg_rows, dtype=abi.SEG_DT)
+    tiles = []
+    for (off, ld, m, n, sb, sc, nc) in blk:
+        for r0 in range(0, m, 32):
+            for c0 in range(0, n, 32):
+                t = np.zeros(1, dtype=abi.TILE_DT)[0]
+                t["c_off"], t["buf_c"], t["ldc"], t["m"], t["n"], t["row0"], t["col0"] = off, 1, ld, min(32, m - r0), min(32, n - c0), r0, c0
+                t["seg_begin"], t["seg_count"], t["pad0"], t["pad1"] = sb, sc, nc, 0
+                tiles.append(t)
+    tarr = np.array(tiles, dtype=abi.TILE_DT)
+    tasks = pl.Tasks(tarr, len(tarr), segs, len(segs), 0)
+    src0, src2 = _rand_z(rng, nel), _rand_z(rng, nel)
+    ref = np.zeros(out_off, dtype=np.complex128)
+    NumpyOps().grouped_gemm([src0, ref, src2] + [None] * 5, (tarr, len(tarr), segs))
+    d0, d2 = hip_ops.to_device(src0), hip_ops.to_device(src2)
+    for balance in (False, True):
+        out = hip_ops.zeros_z(out_off)
+        dev = hip_ops.upload_tasks(tasks, balance=balance)
+        hip_ops.grouped_gemm([d0, out, d2] + [None] * 5, dev)
+        assert np.abs(hip_ops.to_host(out) - ref).max() <= 1e-12 * np.abs(ref).max(), balance
 
 
 def test_mfma_layout_identity_asymmetric(hip_ops):
