@@ -68,12 +68,14 @@ class IDMRGResult:
     history: list = field(default_factory=list)     # (energy per site, delta) per growth step
     engine: object = None        # the last window's engine (device-resident tensors of two unit cells)
     boundary: dict = field(default_factory=dict)    # bL, bR, Lenv, Renv of the last window (what storage needs to re-create it)
+    sweeps: int = 0              # window sweeps run in total
 
 
 def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_per_step=6, init_dimension=8,
-           krylovdim=30, lanczos_tol=1e-10, seed=1234, verbosity=0, min_steps=3):
+           krylovdim=30, lanczos_tol=1e-10, seed=1234, verbosity=0, min_steps=3, warm_start=True):
     """-> IDMRGResult.  `sim` is an OB_Sim / MB_Sim (filling P/Q); truncation by truncdim(chi_full) and/or
-    truncbelow(cutoff) exactly as in the finite engine."""
+    truncbelow(cutoff) exactly as in the finite engine.  warm_start: every window after the first starts from McCulloch's
+    prediction built out of the previous window's halves (`_absorb`) instead of a random state."""
     P, Q = int(sim.P), int(sim.Q)
     B = int(sim.bands)
     sym = models.symmetry_of(sim)
@@ -98,8 +100,15 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
     E_prev, spec_prev, e_site, delta = None, None, float("nan"), float("inf")
     history = []
     eng = None
+    carry = {"sigma": {c: np.ones(n) for c, n in bL.items()}, "Ddag": {c: np.eye(n) for c, n in bL.items()}}
+    guess = None
+    n_sweeps = 0
     for it in range(maxiter):
-        bonds, tensors = mps.random_window(W, bL, bR, init_dimension, seed=seed + it, sym=sym)
+        warm = guess is not None
+        if warm:
+            bonds, tensors = guess
+        else:
+            bonds, tensors = mps.random_window(W, bL, bR, init_dimension, seed=seed + it, sym=sym)
         eng = _engine.DMRG2(ops, cmpo, bonds, tensors, chi_full=chi_full, cutoff=cutoff, krylovdim=krylovdim,
                             lanczos_tol=lanczos_tol, left_env=Lenv, right_env=Renv)
         boundary = {"bL": dict(bL), "bR": dict(bR), "Lenv": Lenv, "Renv": Renv}
@@ -108,7 +117,10 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
         E_sw = None
         for k in range(sweeps_per_step):
             E_new = eng.sweep()
-            if k >= 1 and E_sw is not None and abs(E_new - E_sw) <= 1e-11 * max(abs(E_new), 1.0):
+            n_sweeps += 1
+            # (a predicted window is 1e-6 from its ground state after one sweep and 1e-9 after two; the growth steps, not the
+            # window sweeps, set the accuracy of the fixed point)
+            if k >= 1 and E_sw is not None and abs(E_new - E_sw) <= (1e-8 if warm else 1e-11) * max(abs(E_new), 1.0):
                 break
             E_sw = E_new
         # energy of system_n: <psi|H|psi> of the window state AS STORED (after the truncations of the last sweep),
@@ -124,17 +136,100 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
             print(f"IDMRG2 step {it + 1}: sites {W * (it + 1)}  E/site = {e_site:.10f}  delta = {delta:.3e}  "
                   f"chi = {eng.bond(T).dim_full}")
         E_prev, spec_prev = E, spec
-        if it + 1 >= min_steps and delta < tol:
-            break
+        if (it + 1 >= min_steps and delta < tol) or it + 1 == maxiter:
+            break                                    # (the last window stays as the sweeps left it: centre on site 0)
         # absorb the halves: environments at the centre bond become the new boundaries; the right block's bond is
         # relabelled N -> N + dNw (block order, hence the flat data, unchanged)
         # (each environment carries the bond table it was built on: the left one dates from the rightward pass, the
         # right one from the leftward pass, and truncdim may have kept different counts in between)
-        Lenv, Renv = eng.env_data("L", T), eng.env_data("R", T)
-        bL = dict(eng.env_bond("L", T).dims)
-        bR = {(sym.wrap(N + dNw), j): n for (N, j), n in eng.env_bond("R", T).dims.items()}
+        if warm_start:
+            Lenv, Renv, bL, bR, guess, carry = _absorb(eng, T, sym, dNw, carry)
+            if it == 0:
+                guess = None     # the isolated first window predicts a product of isolated windows: a two-site sweep with a
+                                 # Schmidt cut can stay on it (seen for two decoupled chains snaked onto one); start the
+                                 # second window at random as well, predict from the third on
+        else:
+            Lenv, Renv = eng.env_data("L", T), eng.env_data("R", T)
+            bL = dict(eng.env_bond("L", T).dims)
+            bR = {(sym.wrap(N + dNw), j): n for (N, j), n in eng.env_bond("R", T).dims.items()}
     return IDMRGResult(energy_per_site=e_site, delta=delta, iterations=len(history), unit_cell=T,
-                       bond_dims=eng.bond_dims(), spectrum=spec_prev, history=history, engine=eng, boundary=boundary)
+                       bond_dims=eng.bond_dims(), spectrum=spec_prev, history=history, engine=eng, boundary=boundary,
+                       sweeps=n_sweeps)
+
+
+def _absorb(eng, T, sym, dNw, carry):
+    """Absorb the halves of a converged window and predict the next one (McCulloch, arXiv:0804.2509 sec. II.C).
+
+    The window (sites 0 .. 2T-1, centre on site 0) is brought ONCE into the mixed form  A_0 .. A_{T-1} sigma B'_T .. B_{2T-1}
+    by non-optimising moves: rightwards to the centre bond T (fresh left environment, A's and B'_T = the PAIRED Schmidt
+    bases of bond T), one move back ('left' placement: fresh right environment; its SVD re-chooses the basis, B''_T =
+    D^H B'_T with a unitary D per sector, recovered from the two tensors).  Boundaries of the next window: the left
+    environment in the paired gauge, the right one in the B'' gauge.  Its trial state
+
+        [sigma B'_T] B_{T+1} .. B_{2T-1}  .  [D_prev^H sigma_0^-1 A_0 sigma_1] .. [sigma_{T-1}^-1 A_{T-1} sigma_T D]
+
+    reuses the right half as the new left half and the left half, turned into right-canonical form by the Schmidt values
+    of its own bonds (sigma_0 = the previous step's centre values), as the new right half; labels of the latter move by
+    one window (dNw particles).  All sigma are singular values in the library's Euclidean normalisation (Schmidt value
+    times sqrt(2S+1)).  -> (Lenv, Renv, bL, bR, (bonds, tensors) or None, carry for the next call)."""
+    W = 2 * T
+    kw = dict(optimise=False, record=False)              # (the run's own truncation: the state already satisfies it)
+    tilde = lambda spec: {c: np.asarray(v, dtype=float) * np.sqrt(sym.qdim(c)) for c, v in spec.items()}
+    sh = lambda c: (sym.wrap(c[0] + dNw), c[1])
+    for i in range(T):                                   # centre 0 -> T
+        eng.update_bond(i, +1, "right", **kw)
+    A = [eng.download_site(k) for k in range(T)]
+    sig = [carry["sigma"] if carry else None] + [tilde(eng.spectrum(k)) for k in range(1, T + 1)]
+    CT = eng.download_site(T)                            # sigma_T B'_T
+    Bs = {k: eng.download_site(k) for k in range(T + 1, W)}
+    Lenv, bL = eng.env_data("L", T), dict(eng.env_bond("L", T).dims)
+    ob = [dict(b.dims) for b in eng.bonds]
+    eng.update_bond(T - 1, +1, "left", **kw)             # centre back to T-1: B''_T and the right environment on bond T
+    B2 = eng.download_site(T)
+    Renv, bRt = eng.env_data("R", T), dict(eng.env_bond("R", T).dims)
+    bR = {sh(c): n for c, n in bRt.items()}
+    if bRt != bL or any(len(sig[T].get(c, ())) != n for c, n in bL.items()):
+        return Lenv, Renv, bL, bR, None, None
+    # D^H = B''_T B'_T^H per left sector, B'_T = sigma_T^-1 C_T; made exactly unitary by its polar factor
+    inv = lambda v: np.where(v > 1e-13 * max(float(np.max(v)), 1e-300), 1.0 / np.maximum(v, 1e-300), 0.0)
+    acc = {c: np.zeros((n, n), dtype=np.complex128) for c, n in bL.items()}
+    for (l, s_, r), b2 in B2.items():
+        c1 = CT.get((l, s_, r))
+        if c1 is not None:
+            acc[l] += b2 @ (inv(sig[T][l])[:, None] * c1).conj().T
+    Ddag = {}
+    for c, m in acc.items():                             # (directions of numerically zero weight get an arbitrary completion)
+        u, _, vh = np.linalg.svd(m)
+        Ddag[c] = u @ vh
+    new_carry = {"sigma": sig[T], "Ddag": Ddag}
+    if carry is None:
+        return Lenv, Renv, bL, bR, None, new_carry
+    bonds = [None] * (W + 1)
+    bonds[0] = bL
+    for k in range(1, T + 1):
+        bonds[k] = ob[T + k]
+        bonds[T + k] = {sh(c): n for c, n in ob[k].items()}
+    if bonds[T] != {sh(c): n for c, n in ob[0].items()} or bonds[W] != bR:
+        return (Lenv, Renv, bL, bR, None, new_carry)
+    if any(len(sig[0].get(c, ())) != n for c, n in ob[0].items()):
+        return (Lenv, Renv, bL, bR, None, new_carry)
+    tensors = [None] * W
+    tensors[0] = CT
+    for k in range(1, T):
+        tensors[k] = Bs[T + k]
+    for k in range(T):
+        blk = {}
+        for (l, s_, r), a in A[k].items():
+            if l not in sig[k] or r not in sig[k + 1]:
+                return (Lenv, Renv, bL, bR, None, new_carry)
+            x = (inv(sig[k][l])[:, None] * a) * sig[k + 1][r][None, :]
+            if k == 0:
+                x = carry["Ddag"][l] @ x
+            if k == T - 1:
+                x = x @ Ddag[r].conj().T
+            blk[(sh(l), s_, sh(r))] = x
+        tensors[T + k] = blk
+    return Lenv, Renv, bL, bR, (bonds, tensors), new_carry
 
 
 def _zero_env(bond: dict, levels, side: str, sym=models.SU2U1) -> np.ndarray:

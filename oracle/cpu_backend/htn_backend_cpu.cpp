@@ -67,6 +67,13 @@ int jacobi_cols(cplx* X, int m, int n, int ld, cplx* J, int ldj, double tol, int
         for (int j = 0; j < n; ++j)
             for (int i = 0; i < n; ++i) J[i + (int64_t)j * ldj] = i == j ? 1.0 : 0.0;
     const double thr = tol * tol;
+    // a column below 1e-15 |X|_F is numerically zero (surplus columns of a rank-deficient block, e.g. a centre that is moved
+    // without being optimised): its direction is rounding noise and must not keep the sweep loop alive (same rule as the
+    // HIP kernels, htn_svd.hip)
+    double frob2 = 0.0;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < m; ++i) frob2 += std::norm(X[i + (int64_t)j * ld]);
+    const double zero2 = 1e-30 * frob2;
     for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
         bool rotated = false;
         for (int p = 0; p < n - 1; ++p)
@@ -81,7 +88,7 @@ int jacobi_cols(cplx* X, int m, int n, int ld, cplx* J, int ldj, double tol, int
                     g += std::conj(xp[i]) * xq[i];
                 }
                 const double g2 = std::norm(g);
-                if (g2 <= thr * a * b || g2 == 0.0) continue;
+                if (a <= zero2 || b <= zero2 || g2 <= thr * a * b || g2 == 0.0) continue;
                 rotated = true;
                 const double ag = sqrt(g2);
                 const cplx ph = g / ag;                          // xq <- conj(ph) xq makes the inner product real

@@ -62,3 +62,38 @@ def test_idmrg2_reproduces_a_reference_test_constant_with_the_reference_truncati
     assert abs(e[0] - rec["E_per_site"]) < rec["atol"]            # the reference's own tolerance
     assert abs(e[0] - rec["E_per_site"]) < 5e-4                   # what the shared truncation rule actually gives
     assert delta < 1e-3 and max(api.dim_state(psi)) <= 20
+
+
+def test_predicted_windows_reach_the_fixed_point_of_randomly_started_ones_in_fewer_sweeps():
+    """McCulloch's prediction (idmrg._absorb): every window after the first starts from the previous window's halves.
+    At a truncation fine enough for the fixed point to be well defined (truncbelow(1e-3)) the warm- and the cold-started
+    growth agree on the energy density to 1e-5 and on the centre Schmidt spectrum; the predicted windows need about half
+    the sweeps; and a predicted window is already within 1e-4 (relative) of its converged energy after its FIRST sweep."""
+    from hubbardtn_amd import engine
+    ops = CpuOps()
+    sim = models.OB_Sim([1.0], [4.0], 0.0, 1, 1, 2.0, 50)
+    first, orig = [], engine.DMRG2.sweep
+
+    def spy(self):
+        E = orig(self)
+        self._n = getattr(self, "_n", 0) + 1
+        if self._n == 1:
+            first.append([E])
+        else:
+            first[-1].append(E)
+        return E
+    engine.DMRG2.sweep = spy
+    try:
+        warm = idmrg.idmrg2(ops, sim, cutoff=1e-3, tol=1e-4, maxiter=30, warm_start=True)
+        per_window = [list(w) for w in first]
+        cold = idmrg.idmrg2(ops, sim, cutoff=1e-3, tol=1e-4, maxiter=30, warm_start=False)
+    finally:
+        engine.DMRG2.sweep = orig
+    assert warm.iterations == cold.iterations
+    assert abs(warm.energy_per_site - cold.energy_per_site) < 1e-5
+    assert abs(warm.energy_per_site - (-0.5737)) < 1e-3                 # Lieb-Wu: -0.573729
+    assert warm.sweeps < 0.7 * cold.sweeps
+    for w in per_window[3:]:                                            # (the first windows are far from translation invariant)
+        assert abs(w[0] - w[-1]) < 1e-4 * abs(w[-1])
+    d = idmrg._spectrum_distance(warm.spectrum, cold.spectrum, 0)
+    assert d < 3e-3                                                     # (one multiplet next to the 1e-3 threshold)
