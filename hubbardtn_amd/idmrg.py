@@ -72,13 +72,19 @@ class IDMRGResult:
 
 
 def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_per_step=6, init_dimension=8,
-           krylovdim=30, lanczos_tol=1e-10, seed=1234, verbosity=0, min_steps=3, warm_start=True):
+           krylovdim=30, lanczos_tol=1e-10, seed=1234, verbosity=0, min_steps=3, warm_start=None):
     """-> IDMRGResult.  `sim` is an OB_Sim / MB_Sim (filling P/Q); truncation by truncdim(chi_full) and/or
-    truncbelow(cutoff) exactly as in the finite engine.  warm_start: every window after the first starts from McCulloch's
-    prediction built out of the previous window's halves (`_absorb`) instead of a random state."""
+    truncbelow(cutoff) exactly as in the finite engine.  warm_start: every window after the second starts from McCulloch's
+    prediction built out of the previous window's halves (`_absorb`) instead of a random state.  Default: on for the
+    SU(2)-symmetric modes; off for the spinful U(1) x U(1) mode, whose growth under a crude Schmidt cut has several
+    self-consistent fixed points (symmetry-broken windows whose multiplets the cut has split) -- random restarts wander
+    between them and find lower ones than a prediction that hands one of them on (two-band test/Spin.jl case: -0.61 against
+    -0.55)."""
     P, Q = int(sim.P), int(sim.Q)
     B = int(sim.bands)
     sym = models.symmetry_of(sim)
+    if warm_start is None:
+        warm_start = sym.kind != 1
     T = cell_sites(sim)                      # sites per unit cell
     W = 2 * T
     dNw = (W * P) // Q                       # particles in a window (integer: the cell length is a multiple of Q)
@@ -102,7 +108,7 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
     eng = None
     carry = {"sigma": {c: np.ones(n) for c, n in bL.items()}, "Ddag": {c: np.eye(n) for c, n in bL.items()}}
     guess = None
-    n_sweeps = 0
+    n_sweeps = stall = 0
     for it in range(maxiter):
         warm = guess is not None
         if warm:
@@ -144,10 +150,16 @@ def idmrg2(ops, sim, chi_full=None, cutoff=0.0, tol=1e-6, maxiter=100, sweeps_pe
         # right one from the leftward pass, and truncdim may have kept different counts in between)
         if warm_start:
             Lenv, Renv, bL, bR, guess, carry = _absorb(eng, T, sym, dNw, carry)
-            if it == 0:
-                guess = None     # the isolated first window predicts a product of isolated windows: a two-site sweep with a
-                                 # Schmidt cut can stay on it (seen for two decoupled chains snaked onto one); start the
-                                 # second window at random as well, predict from the third on
+            # a growth that neither converges nor moves (the spinful two-band model with the crude Schmidt cut can lock into
+            # a poor, symmetry-broken window that the prediction then hands on unchanged) gets a random window again
+            if len(history) >= 2 and delta > 10.0 * tol and abs(delta - history[-2][1]) <= 0.05 * delta:
+                stall += 1
+            else:
+                stall = 0
+            if it == 0 or stall >= 2:
+                guess = None     # (it == 0: the isolated first window predicts a product of isolated windows: a two-site
+                stall = 0        # sweep with a Schmidt cut can stay on it -- seen for two decoupled chains snaked onto one --
+                                 # so the second window starts at random as well, prediction from the third on)
         else:
             Lenv, Renv = eng.env_data("L", T), eng.env_data("R", T)
             bL = dict(eng.env_bond("L", T).dims)
