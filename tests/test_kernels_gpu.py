@@ -256,6 +256,43 @@ def test_jacobi_svd_qr_preconditioned(hip_ops, shapes, multi):
         assert np.abs(resid).max() <= 1e-12 * ref[0] ** 2
 
 
+def test_large_block_svd_result_does_not_depend_on_the_sweep_hint(hip_ops):
+    """htn_svd_opts.sweeps_hint only bounds the SPECULATIVE enqueue of outer sweeps (the sweep expected to be the last is
+    not followed by an empty one): singular values, vectors and the reported sweep count are bit-identical for no hint,
+    the right hint, a hint that is too small (extra sweeps are then enqueued one at a time) and one that is too large"""
+    rng = np.random.default_rng(21)
+    shapes = [(230, 230), (300, 170)]
+    desc = np.zeros(len(shapes), dtype=abi.SVD_DT)
+    go = vo = so = 0
+    mats = []
+    for i, (m0, n0) in enumerate(shapes):
+        r = min(m0, n0)
+        desc[i] = (go, vo, so, n0, r, abi.SVD_QRCP, m0)
+        U, _ = np.linalg.qr(_rand_z(rng, m0 * r).reshape(m0, r))
+        W, _ = np.linalg.qr(_rand_z(rng, n0 * r).reshape(n0, r))
+        mats.append((U * 10.0 ** (-10 * np.arange(r) / (r - 1))) @ W.conj().T)
+        go, vo, so = go + m0 * n0, vo + ((n0 + 63) // 64 * 64) * r, so + r
+    src = hip_ops.to_device(np.concatenate([M.T.reshape(-1) for M in mats]))
+    d_desc = hip_ops.to_device(desc)
+    runs = []
+    used0 = None
+    for hint in (0, None, 2, 30):
+        dG = src.clone()
+        dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
+        used = hip_ops.jacobi_svd(dG, dV, dS, d_desc, len(shapes), 300, 40, 1e-14, info, desc_host=desc,
+                                  sweeps_hint=used0 if hint is None else hint)
+        if used0 is None:
+            used0 = used
+        runs.append((used, hip_ops.to_host(dS), hip_ops.to_host(dG), hip_ops.to_host(info)))
+    assert 3 <= used0 <= 12
+    for used, S, G, inf in runs[1:]:
+        assert used == used0 and np.array_equal(S, runs[0][1]) and np.array_equal(G, runs[0][2]) and np.array_equal(inf, runs[0][3])
+    for i, (m0, n0) in enumerate(shapes):
+        ref = np.linalg.svd(mats[i], compute_uv=False)
+        got = np.sort(runs[0][1][desc[i]["s_off"]:desc[i]["s_off"] + min(m0, n0)])[::-1]
+        assert np.abs(got - ref).max() <= 1e-13 * ref[0]
+
+
 @pytest.mark.parametrize("multi", [False, True])
 def test_jacobi_svd_rank_deficient_large_blocks(hip_ops, multi):
     """blocks whose numerical rank is below min(m0, n0) -- the two-site block of a bond whose neighbour is not
