@@ -17,6 +17,13 @@ __global__ __launch_bounds__(256) void k_scale_z(double2* __restrict__ x, int64_
     }
 }
 
+// device -> host-mapped pinned memory by a kernel: a small hipMemcpyAsync D2H goes through the SDMA engine and costs
+// ~100 us end to end on this part (measured per bond for the ~10 KB of singular values); zero-copy stores cost ~10
+__global__ __launch_bounds__(256) void k_copy_words(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n) {
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) dst[j] = src[j];
+    __threadfence_system();
+}
+
 // ---- RCCL through dlsym: torch (when it is the host's plumbing) has already loaded its own librccl; binding at run
 // time keeps ONE copy of the library in the process, and a plain C caller gets /opt/rocm/lib/librccl.so ----------------
 struct Rccl {
@@ -64,7 +71,8 @@ struct HipBackend : htn::Backend {
     void* comm = nullptr;
     char* stage = nullptr;                        // pinned host staging ring of upload()
     size_t stage_cap = (size_t)32 << 20, stage_pos = 0;
-    char* land = nullptr;                         // pinned landing buffer of download()
+    char* land = nullptr;                         // pinned, device-mapped landing buffer of download()
+    char* land_dev = nullptr;
     size_t land_cap = (size_t)4 << 20;
 
     ~HipBackend() override {
@@ -156,8 +164,17 @@ struct HipBackend : htn::Backend {
             stage_pos = 0;
             return 0;
         }
-        if (!land) HIP_TRY(hipHostMalloc((void**)&land, land_cap));
-        HIP_TRY(hipMemcpyAsync(land, src, bytes, hipMemcpyDeviceToHost, st));
+        if (!land) {
+            HIP_TRY(hipHostMalloc((void**)&land, land_cap, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void**)&land_dev, land, 0));
+        }
+        if (bytes <= ((size_t)256 << 10) && ((uintptr_t)src & 3) == 0) {        // (device blocks are 256-byte granular: the
+            const size_t words = (bytes + 3) / 4;                                //  last word may be read past `bytes`)
+            hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((words + 255) / 256, 64)), dim3(256), 0, st,
+                               (uint32_t*)land_dev, (const uint32_t*)src, words);
+            HIP_TRY(hipGetLastError());
+        } else
+            HIP_TRY(hipMemcpyAsync(land, src, bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(htn_stream_spin(st));
         memcpy(dst, land, bytes);
         stage_pos = 0;                        // everything enqueued before has completed: the ring is free again
