@@ -1342,16 +1342,33 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     char* h = (char*)g_js.pinned;
     JacPairItem* h_items = (JacPairItem*)h;
     int* h_ids = (int*)(h + sizeof(JacPairItem) * n_items_max);
-    int* h_slot = (int*)((char*)h_ids + 16 * ((nl * 4 + 15) / 16));
+    int* h_slot = h_ids + nl;                        // [ids | slot] contiguous like the device copy: ONE upload
     volatile int* h_active = (volatile int*)(h_slot + n_blocks);
     volatile int* h_rank = h_active + (max_sweeps + 1);
     for (int b = 0; b < n_blocks; ++b) h_slot[b] = -1;
     for (int li = 0; li < nl; ++li) h_slot[large[li]] = li;
     for (int li = 0; li < nl; ++li) h_ids[li] = large[li];
     for (int k = 0; k <= max_sweeps; ++k) h_active[k] = 1;
-    HIP_TRY(hipMemcpyAsync(d_ids, h_ids, sizeof(int) * nl, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_slot, h_slot, sizeof(int) * n_blocks, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(d_done, 0, sizeof(int) * nl, st));
+    // every small copy / fill is a separate blit launch on the stream: they are enqueued BEFORE the QR (nothing here
+    // depends on it unless a rank cut sizes the tournament), merged where the regions are contiguous
+    HIP_TRY(hipMemcpyAsync(d_ids, h_ids, sizeof(int) * (nl + n_blocks), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_ratio, 0, 16 * (size_t)nl, st));          // ratio (8 nl) | done (4 nl) | sweeps (4 nl)
+    const double cut2 = g_jac_cut * g_jac_cut;
+    std::vector<int> n_eff(nl);
+    for (int li = 0; li < nl; ++li) n_eff[li] = desc_host[large[li]].n;
+    std::vector<size_t> r_off;
+    auto upload_rounds = [&]() -> int {
+        build_rounds(n_eff.data());
+        r_off.resize(rounds.size());
+        size_t pos = 0;
+        for (size_t r = 0; r < rounds.size(); ++r) {
+            r_off[r] = pos;
+            for (auto& it : rounds[r]) h_items[pos++] = it;
+        }
+        if (pos) HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(JacPairItem) * pos, hipMemcpyHostToDevice, st));
+        return 0;
+    };
+    if (cut2 <= 0.0 && upload_rounds()) return 1;
     // large blocks: pivoted QR on this stream, then the sweeps; the small blocks run their whole SVD beside
     // them on the forked stream and join before the call returns
     HIP_TRY(hipEventRecord(g_js.ev_fork, st));
@@ -1360,7 +1377,6 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
                        (double2*)G, (double2*)Vj, S, desc, max_sweeps, tol, info_dev, lds_elems, (const int*)d_slot,
                        g_jac_cut * g_jac_cut);
     HIP_TRY(hipEventRecord(g_js.ev_join, g_js.aux));
-    const double cut2 = g_jac_cut * g_jac_cut;
     {
         int max_m0 = 0;
         for (int li = 0; li < nl; ++li) max_m0 = std::max(max_m0, (int)desc_host[large[li]].pad);
@@ -1368,30 +1384,15 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         hipLaunchKernelGGL(k_qr_large, dim3(nl), dim3(JAC_THREADS), qr_lds, st, (double2*)G, (double2*)Vj, desc, d_ids,
                            d_perm, d_zero, cut2, (int*)h_rank);
     }
-    std::vector<int> n_eff(nl);
-    for (int li = 0; li < nl; ++li) n_eff[li] = desc_host[large[li]].n;
     if (cut2 > 0.0) {        // the tournament is sized by the ranks the QR found: wait for them (one sync per call)
         HIP_TRY(hipEventRecord(g_js.ev_sweep[0], st));
         HIP_TRY(htn_event_spin(g_js.ev_sweep[0]));
         for (int li = 0; li < nl; ++li) n_eff[li] = std::min(n_eff[li], (int)h_rank[li]);
+        if (upload_rounds()) return 1;
     }
-    build_rounds(n_eff.data());
-    size_t n_items = 0;
-    for (auto& r : rounds) n_items += r.size();
-    std::vector<size_t> r_off(rounds.size());
-    {
-        size_t pos = 0;
-        for (size_t r = 0; r < rounds.size(); ++r) {
-            r_off[r] = pos;
-            for (auto& it : rounds[r]) h_items[pos++] = it;
-        }
-    }
-    if (n_items) HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(JacPairItem) * n_items, hipMemcpyHostToDevice, st));
     const size_t gram_lds_bytes = (size_t)(16 * (max_mp + 1) + JG_GU_ELEMS) * sizeof(double2);
     // sweeps are enqueued one ahead of the host's knowledge (depth-1 pipeline, like htn_lanczos_z): the device
     // decides convergence itself (k_jacobi_check), the host only learns when to stop enqueuing
-    HIP_TRY(hipMemsetAsync(d_ratio, 0, 8 * nl, st));
-    HIP_TRY(hipMemsetAsync(d_sw, 0, sizeof(int) * nl, st));
     const double thr = std::max(tol * tol, 0.1 * tol);          // quadratic convergence, see jacobi_sweeps
     auto enqueue_sweep = [&](int sweep) {
         for (size_t r = 0; r < rounds.size(); ++r)
