@@ -142,6 +142,7 @@ def _mat4(entries):
 _A_UP = _mat4({(0, 1): 1, (2, 3): 1})            # a_up |up> = |0>, a_up |updn> = |dn>
 _A_DN = _mat4({(0, 2): 1, (1, 3): -1})           # a_dn |dn> = |0>, a_dn |updn> = -|up>
 _F4 = np.diag([1.0, -1.0, -1.0, 1.0])
+_N_UP, _N_DN = np.diag([0.0, 1.0, 0.0, 1.0]), np.diag([0.0, 0.0, 1.0, 1.0])
 SITE_MULT_U1 = ((0, 0), (1, 1), (1, -1), (2, 0))
 SITE_OPS_U1 = {
     "id": (0, 0, np.eye(4)),
@@ -151,12 +152,27 @@ SITE_OPS_U1 = {
     "sz": (0, 0, np.diag([0.0, 0.5, -0.5, 0.0])),                   # Sz(), src:329-339
     "cdagF_up": (+1, +1, _A_UP.T @ _F4), "c_up": (-1, -1, _A_UP), "Fc_up": (-1, -1, _F4 @ _A_UP), "cdag_up": (+1, +1, _A_UP.T),
     "cdagF_dn": (-1, +1, _A_DN.T @ _F4), "c_dn": (+1, -1, _A_DN), "Fc_dn": (+1, -1, _F4 @ _A_DN), "cdag_dn": (-1, +1, _A_DN.T),
+    # exchange terms: spin ladder operators S+ = c+_up c_dn, S- = c+_dn c_up and the on-site pair D+ = c+_up c+_dn
+    "sp": (+2, 0, _A_UP.T @ _A_DN), "sm": (-2, 0, _A_DN.T @ _A_UP),
+    "pair_dag": (0, +2, _A_UP.T @ _A_DN.T), "pair": (0, -2, _A_DN @ _A_UP),
+    # density-assisted ladder operators n_{-s} c+_s, n_{-s} c_s (three-equal-index terms)
+    "cdagF_up_d": (+1, +1, _N_DN @ _A_UP.T @ _F4), "c_up_d": (-1, -1, _N_DN @ _A_UP),
+    "Fc_up_d": (-1, -1, _F4 @ _N_DN @ _A_UP), "cdag_up_d": (+1, +1, _N_DN @ _A_UP.T),
+    "cdagF_dn_d": (-1, +1, _N_UP @ _A_DN.T @ _F4), "c_dn_d": (+1, -1, _N_UP @ _A_DN),
+    "Fc_dn_d": (+1, -1, _F4 @ _N_UP @ _A_DN), "cdag_dn_d": (-1, +1, _N_UP @ _A_DN.T),
 }
 # c+_{i s} c_{j s} = (a+_s F)_i F.. (a_s)_j ;  c+_{j s} c_{i s} = (F a_s)_i F.. (a+_s)_j   (i < j): unit factors
 TERM_CHANNELS_U1 = {
     "hop": (("hop_up+", (+1, +1), "cdagF_up", "F", "c_up", 1.0), ("hop_up-", (-1, -1), "Fc_up", "F", "cdag_up", 1.0),
             ("hop_dn+", (+1, -1), "cdagF_dn", "F", "c_dn", 1.0), ("hop_dn-", (-1, +1), "Fc_dn", "F", "cdag_dn", 1.0)),
     "nn": (("nn", (0, 0), "n", "id", "n", 1.0),),
+    # S_i . S_j = Sz Sz + (S+ S- + S- S+) / 2;  D+_i D_j + h.c.;  density-assisted hopping per spin (all CG factors 1)
+    "ss": (("szsz", (0, 0), "sz", "id", "sz", 1.0), ("s+-", (0, +2), "sp", "id", "sm", 0.5), ("s-+", (0, -2), "sm", "id", "sp", 0.5)),
+    "pair": (("pair+", (+2, 0), "pair_dag", "id", "pair", 1.0), ("pair-", (-2, 0), "pair", "id", "pair_dag", 1.0)),
+    "dhopR": (("dRu+", (+1, +1), "cdagF_up", "F", "c_up_d", 1.0), ("dRu-", (-1, -1), "Fc_up", "F", "cdag_up_d", 1.0),
+              ("dRd+", (+1, -1), "cdagF_dn", "F", "c_dn_d", 1.0), ("dRd-", (-1, +1), "Fc_dn", "F", "cdag_dn_d", 1.0)),
+    "dhopL": (("dLu+", (+1, +1), "cdagF_up_d", "F", "c_up", 1.0), ("dLu-", (-1, -1), "Fc_up_d", "F", "cdag_up", 1.0),
+              ("dLd+", (+1, -1), "cdagF_dn_d", "F", "c_dn", 1.0), ("dLd-", (-1, +1), "Fc_dn_d", "F", "cdag_dn", 1.0)),
 }
 
 

@@ -155,3 +155,39 @@ def test_spinful_reference_constant_through_idmrg2(cpu_ops):
     up, dn = api.density_spin(psi)
     n = api.density_state(psi)
     assert abs(n.sum() / 2 - (up + dn).sum() / len(H)) < 1e-8                  # test/Spin.jl:76-79
+
+
+def test_spinful_exchange_and_three_equal_index_terms(cpu_ops):
+    """exchange J (S.S = Sz Sz + (S+ S- + S- S+)/2, pair hopping) and the density-assisted hopping of U13 / Uijjj in the
+    fZ2 x U(1) x U(1) mode: the abelian MPO equals, densely, the SU(2) x U(1) MPO of the same model (which
+    tests/test_host_cpu.py pins against the second-quantised Kanamori / n_{-s} c+_s c_s forms), one band and two bands;
+    the engine's untruncated energies are eigenvalues of the dense matrix in the (N, Sz = 0) sector -- the lowest one in
+    the spinful mode, the lowest spin singlet in the SU(2) mode (Hund's exchange puts a triplet below it here)"""
+    from oracle import mpo as ompo
+    as_dict = lambda Hm: [{"left": list(W.left), "right": list(W.right), "entries": list(W.entries)} for W in Hm]
+    L, t, u, J, U13 = 4, [1.0, 0.2], [4.0, 0.5], [0.3, 0.1], [0.25, -0.15]
+    Ha = models.hamiltonian(models.OB_Sim(t, u, 0.1, J, 1, 1, 2.0, 8, spin=True, U13=U13), L)
+    Hs = models.hamiltonian(models.OB_Sim(t, u, 0.1, J, 1, 1, 2.0, 8, U13=U13), L)
+    Ma = _dense_from_abelian_mpo(Ha)
+    assert np.abs(Ma - ompo.mpo_to_dense(as_dict(Hs))).max() < 1e-13 and np.abs(Ma - Ma.T).max() < 1e-14
+    B, cells = 2, 2
+    tm = np.array([[0.1, 0.7, 0.4, 0.0], [0.7, -0.2, 0.3, 0.2]])
+    um = np.array([[3.0, 1.0, 0.0, 0.0], [1.0, 2.5, 0.0, 0.0]])
+    Jm = np.array([[0.0, 0.3, 0.1, 0.0], [0.3, 0.0, 0.2, 0.05]])
+    U13_OS = np.array([[0.0, 0.25], [-0.15, 0.0]])
+    mk = lambda spin: models.hamiltonian(models.MB_Sim(tm, um, Jm, U13_OS, 1, 1, 2.0, 8, spin=spin), cells)
+    assert np.abs(_dense_from_abelian_mpo(mk(True)) - ompo.mpo_to_dense(as_dict(mk(False)))).max() < 1e-13
+    E, Ls = {}, 6
+    for spin in (False, True):
+        H = models.hamiltonian(models.OB_Sim(t, u, 0.0, J, 1, 1, 2.0, 8, spin=spin, U13=U13), Ls)
+        bonds, tens = mps.random_mps(Ls, (Ls, 0), 64, seed=2, sym=H.sym)
+        eng = engine.DMRG2(cpu_ops, H, bonds, tens, chi_full=None, lanczos_tol=1e-12)
+        for _ in range(4):
+            E[spin] = eng.sweep()
+        if spin:
+            M = _dense_from_abelian_mpo(H)
+    diag = lambda op: np.sum([np.kron(np.kron(np.ones(4 ** i), op), np.ones(4 ** (Ls - 1 - i))) for i in range(Ls)], axis=0)
+    keep = np.nonzero((np.abs(diag(np.array([0.0, 1.0, 1.0, 2.0])) - Ls) < 1e-9) & (np.abs(diag(np.array([0.0, 0.5, -0.5, 0.0]))) < 1e-9))[0]
+    w = np.linalg.eigvalsh(M[np.ix_(keep, keep)])
+    assert abs(E[True] - w[0]) < 1e-9 * abs(w[0])
+    assert E[False] > E[True] - 1e-9 and np.abs(w - E[False]).min() < 1e-8
