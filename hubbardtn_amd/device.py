@@ -157,7 +157,7 @@ class HipOps:
     # ---- kernels ----------------------------------------------------------------------------
     def upload_tasks(self, tasks, balance=False):
         """tasks: Tasks (tests/ref_planner.py) -> (tiles_dev, ntiles, segs_dev).  balance=True applies the library's own
-        launch balancing pass (htn_balance_tiles: split-K parts for long tiles + XCD-aware order) and makes sure the
+        launch balancing pass (htn_balance_tiles: spatial and split-K tile cuts + placement-aware order) and makes sure the
         split-K workspace is large enough; grouped_gemm passes the workspace in buffer slot 7."""
         tiles_h, ntiles = tasks.tiles, tasks.ntiles
         if balance and ntiles > 0:

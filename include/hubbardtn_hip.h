@@ -386,9 +386,10 @@ int32_t htn_mps_env_bond(const htn_mps* mps, int32_t side, int32_t b, htn_sector
  * stage 0 = Z stage (may be empty), 1 = Y stage.  Returns counts through n_tiles / n_segs; tiles / segs may be NULL. */
 int htn_plan_apply_dump(htn_mps* mps, int32_t i, int32_t stage, int32_t* n_tiles, htn_tile* tiles_host, int32_t* n_segs,
                         htn_seg* segs_host, int64_t* z_size, int64_t* flops);
-/* the launch load-balancing pass the engine applies to every task list before upload (HIP backend): tiles with more K
- * slabs than a CU's fair share are cut into split-K parts (htn_tile.part / nparts / ws_slot / ticket), records ordered
- * longest first and dealt XCD-aware.  Returns the number of workspace slabs the balanced list needs (bufs[HTN_BUF_WS]
+/* the launch load-balancing pass the engine applies to every task list before upload (HIP backend): long tiles of 2 or 4
+ * quadrants (16 x 16) are cut into one-quadrant tiles sharing their segment list, tiles still longer than a CU's fair
+ * share into split-K parts (htn_tile.part / nparts / ws_slot / ticket); the records are then dealt in layers of n_cus,
+ * longest to the least loaded CU, XCD-aware.  Returns the number of workspace slabs the balanced list needs (bufs[HTN_BUF_WS]
  * must then hold HTN_WS_ELEMS(slabs) elements with the ticket region zeroed), -1 on error; *n_out = number of records
  * (out may be NULL to query it). */
 int32_t htn_balance_tiles(const htn_tile* tiles_host, int32_t n_tiles, int32_t n_cus, htn_tile* out_host, int32_t out_cap,

@@ -1,6 +1,6 @@
 """micro-benchmark of the H_eff apply (k_grouped_gemm_z) on the SURVEY App. D proxy sector table, scaled.
 Task lists come from the Python statement of the planner (tests/ref_planner.py); `balance` applies the library's launch
-balancing pass (htn_balance_tiles: split-K parts + XCD-aware order; knobs HTN_GEMM_CAP_ROUNDS / HTN_GEMM_XCD)."""
+balancing pass (htn_balance_tiles: tile cuts + placement-aware order; knobs HTN_GEMM_CAP / HTN_GEMM_CAPK / HTN_GEMM_XCD / HTN_GEMM_LAYERS)."""
 import os
 import sys
 import time
@@ -59,7 +59,7 @@ def run(ops, scale, t=(1.0,), reps=30, balance=True, evict=False):
         tot += e0.elapsed_time(e1) * 1e3
     us = tot / reps
     fl = ty.flops + (tz.flops if tz is not None else 0)
-    print(f"scale {scale:4.1f} t={t} balance={int(balance)} evict={int(evict)} cap={os.environ.get('HTN_GEMM_CAP_ROUNDS', 'auto')} "
+    print(f"scale {scale:4.1f} t={t} balance={int(balance)} evict={int(evict)} cap={os.environ.get('HTN_GEMM_CAP', 'auto')} "
           f"xcd={os.environ.get('HTN_GEMM_XCD', '1')}: chi_full {bl.dim_full:5d} |theta| {tl.size:8d} tiles {ty.ntiles:5d} -> {dy[1]:5d} "
           f"segs {ty.nsegs:6d} GFLOP {fl / 1e9:7.3f}  {us:8.1f} us  {fl / us / 1e6:7.2f} TFLOP/s", flush=True)
 
