@@ -292,15 +292,21 @@ class MPOSite:
     entries: list     # [(wl, wr, opname, coef)]
 
 
-def _build_mpo(nsites, onsite, pairs, sym=None, merge=True):
+def _build_mpo(nsites, onsite, pairs, sym=None, merge=True, strings=()):
     """onsite: {site: [(opname, coef)]}; pairs: list of (i, j, kind, coef) with i < j (0-based), kind in the symmetry's
     term channels.  Finite-state-machine MPO: level 0 = nothing applied ('start'), last = complete ('final'), in
     between one level per OPEN channel.  merge=True (default): all terms of one channel type that open on the same site
     share ONE level, which lives until their farthest closing site and closes with each term's own coefficient --
     sum_j t_ij c+_i c_j needs one "c+_i emitted" level, not one per j.  The Hamiltonian is the same operator; the MPO
     bond is narrower (range-r hopping: r instead of r (r + 1) / 2 levels per channel type), and the H_eff apply costs
-    proportionally less.  merge=False reproduces the reference's uncompressed sum of per-term MPOs (`H += h`, src:439)."""
+    proportionally less.  merge=False reproduces the reference's uncompressed sum of per-term MPOs (`H += h`, src:439).
+    strings (abelian mode only): [(coef, {site: 4 x 4 matrix})] -- a product of local operators on a contiguous range of
+    sites (`_jw_string`); every string gets its own chain of levels labelled by the charge accumulated from the left."""
     sym = sym or SU2U1
+    if strings:
+        sym, onsite, str_ent, str_lvl = _string_entries(sym, nsites, dict(onsite), strings)
+    else:
+        str_ent, str_lvl = {}, {}
     coefs = {}
     for (i, j, kind, coef) in pairs:
         if coef == 0.0:
@@ -324,8 +330,9 @@ def _build_mpo(nsites, onsite, pairs, sym=None, merge=True):
             return [("start",)], [(0, 0)]
         if b == nsites:
             return [("final",)], [(0, 0)]
-        names = [("start",)] + chans[b] + [("final",)]
-        return names, [(0, 0)] + [chan_def[c][0] for c in chans[b]] + [(0, 0)]
+        extra = str_lvl.get(b, [])
+        names = [("start",)] + chans[b] + [n_ for n_, _ in extra] + [("final",)]
+        return names, [(0, 0)] + [chan_def[c][0] for c in chans[b]] + [q_ for _, q_ in extra] + [(0, 0)]
 
     sites = []
     for s in range(nsites):
@@ -341,8 +348,10 @@ def _build_mpo(nsites, onsite, pairs, sym=None, merge=True):
         for (op, coef) in onsite.get(s, []):
             if coef != 0.0:
                 ent.append((il[("start",)], ir[("final",)], op, coef))
+        for (nl_, nr_, op, coef) in str_ent.get(s, []):
+            ent.append((il[nl_], ir[nr_], op, coef))
         for name in nr:
-            if name[0] in ("start", "final"):
+            if name[0] in ("start", "final", "str"):
                 continue
             q, op_open, op_pass, op_close, closings = chan_def[name]
             if name[1] == s:
@@ -350,13 +359,89 @@ def _build_mpo(nsites, onsite, pairs, sym=None, merge=True):
             else:
                 ent.append((il[name], ir[name], op_pass, 1.0))
         for name in nl:
-            if name[0] in ("start", "final"):
+            if name[0] in ("start", "final", "str"):
                 continue
             q, op_open, op_pass, op_close, closings = chan_def[name]
             if s in closings:
                 ent.append((il[name], ir[("final",)], op_close, closings[s]))
         sites.append(MPOSite(ql, qr, ent))
     return MPO(sites, sym)
+
+
+def _jw_string(ops):
+    """product of local fermionic / bosonic operators, leftmost factor first: ops = [(site, 4 x 4 matrix, odd)] with
+    c_p = (prod_{q < p} F_q) a_p  ->  {site: matrix} over the contiguous range min..max of the sites touched: the factor of
+    site q is the ordered product of a_p (q = p), F (q < p, odd operator) or 1 -- no sign bookkeeping needed"""
+    lo, hi = min(p for p, _, _ in ops), max(p for p, _, _ in ops)
+    M = {q: np.eye(4) for q in range(lo, hi + 1)}
+    for (p, a, odd) in ops:
+        for q in range(lo, hi + 1):
+            if q == p:
+                M[q] = M[q] @ a
+            elif q < p and odd:
+                M[q] = M[q] @ _F4
+    return M
+
+
+def _charge_u1(m):
+    """(dN, d 2Sz) of a 4 x 4 matrix in the spinful basis, or None if it is zero"""
+    nz = np.argwhere(np.abs(m) > 0)
+    if len(nz) == 0:
+        return None
+    q = {(SITE_MULT_U1[o][0] - SITE_MULT_U1[i][0], SITE_MULT_U1[o][1] - SITE_MULT_U1[i][1]) for o, i in nz}
+    if len(q) != 1:
+        raise ValueError("operator string with a local factor of mixed charge")
+    return q.pop()
+
+
+def _string_entries(sym, nsites, onsite, strings):
+    """-> (symmetry with the strings' local matrices registered as site operators, onsite incl. one-site strings,
+    {site: [(left level name, right level name, op, coef)]}, {bond: [(level name, label)]})"""
+    if sym.kind != 1:
+        raise NotImplementedError("operator strings (U112 / U1111 terms) are available in the spinful mode (spin=true) only")
+    ops, names = dict(sym.site_ops), {}
+
+    def opname(m):
+        q = _charge_u1(m)
+        key = m.tobytes()
+        if key not in names:
+            names[key] = f"x{len(names)}"
+            ops[names[key]] = (q[1], q[0], m.copy())
+        return names[key]
+    ent, lvl = {}, {}
+    for idx, (coef, mats) in enumerate(strings):
+        if coef == 0.0 or any(_charge_u1(m) is None for m in mats.values()):
+            continue
+        sites = sorted(mats)
+        if sites[0] < 0 or sites[-1] >= nsites:
+            continue
+        if len(sites) == 1:
+            if _charge_u1(mats[sites[0]]) != (0, 0):
+                raise ValueError("one-site operator string that changes the charge")
+            onsite.setdefault(sites[0], []).append((opname(mats[sites[0]]), coef))
+            continue
+        acc, prev = (0, 0), ("start",)
+        for p in sites:
+            q = _charge_u1(mats[p])
+            acc = (acc[0] + q[0], acc[1] + q[1])
+            last = p == sites[-1]
+            cur = ("final",) if last else ("str", idx, p + 1)
+            if last and acc != (0, 0):
+                raise ValueError("operator string that changes the total charge")
+            if not last:
+                lvl.setdefault(p + 1, []).append((cur, acc))
+            ent.setdefault(p, []).append((prev, cur, opname(mats[p]), coef if last else 1.0))
+            prev = cur
+    sym2 = Symmetry(sym.kind, sym.name, sym.site_mult, ops, sym.channels, sym.site_electrons)
+    return sym2, onsite, ent, lvl
+
+
+def _hop_product(strings, coef, a, b, c, d, herm=True):
+    """coef * E_ab E_cd (+ h.c.), E_ab = sum_s c+_{a s} c_{b s}, as spinful operator strings (any coincidences of the sites)"""
+    for (X, Y) in ((_A_UP, _A_UP), (_A_UP, _A_DN), (_A_DN, _A_UP), (_A_DN, _A_DN)):
+        strings.append((coef, _jw_string([(a, X.T, True), (b, X, True), (c, Y.T, True), (d, Y, True)])))
+        if herm:
+            strings.append((coef, _jw_string([(d, Y.T, True), (c, Y, True), (b, X.T, True), (a, X, True)])))
 
 
 def _exchange(pairs, i, j, J):
@@ -493,5 +578,33 @@ def hamiltonian(sim: Simulation, L: int):
                             i, j = site(bi, cell), site(bf, cell + r)
                             _assisted_hop(pairs, i, j, 0.5 * (M[bi, bf, 0] + M[bi, bf, 1]))      # density on j
                             _assisted_hop(pairs, j, i, 0.5 * (M[bi, bf, 2] + M[bi, bf, 3]))      # density on i
-        return _build_mpo(n, onsite, pairs, sym)
+        strings = []
+        orb = lambda o, cell: site((o - 1) % B, cell + (o - 1) // B)                      # 1-based orbital over r B -> chain site
+        for name in ("U112", "U1111"):
+            for key, U in (sim.kwargs.get(name) or {}).items():
+                i, j, k, l = (int(x) for x in key)
+                if min(i, j, k, l) > B:
+                    raise ValueError("At least one index in every tuple (i,j,k,l) has to be at site 0.")      # src:738, 789
+                distinct = len({i, j, k, l})
+                if distinct != (3 if name == "U112" else 4):
+                    raise ValueError("Two indices should be the same. Not more, not less." if name == "U112"
+                                     else "All indices must be different.")                                  # src:740, 791
+                for cell in range(L):
+                    o = lambda x: orb(x, cell)
+                    if max(o(i), o(j), o(k), o(l)) >= n:
+                        continue
+                    if name == "U1111":            # Uijkl, src:782-809: 0.5 U E_il E_jk (the dictionary holds every permutation)
+                        _hop_product(strings, 0.5 * U, o(i), o(l), o(j), o(k), herm=False)
+                    elif k == l:                   # Uijkk, src:732-780: C1 + C1'
+                        _hop_product(strings, 0.5 * U, o(j), o(k), o(i), o(k))
+                    elif j == k:                   # C2 + C2': hopping i <- l dressed with the density of orbital j
+                        for X in (_A_UP, _A_DN):
+                            nj = np.diag([0.0, 1.0, 1.0, 2.0])
+                            strings.append((U, _jw_string([(o(i), X.T, True), (o(l), X, True), (o(j), nj, False)])))
+                            strings.append((U, _jw_string([(o(j), nj, False), (o(l), X.T, True), (o(i), X, True)])))
+                    elif j == l:                   # C3 + C3'
+                        _hop_product(strings, 0.5 * U, o(j), o(k), o(i), o(j))
+                    else:
+                        raise ValueError("U112: the repeated index must be k = l, j = k or j = l")
+        return _build_mpo(n, onsite, pairs, sym, strings=strings)
     raise TypeError(f"unsupported simulation type {type(sim)}")
