@@ -37,6 +37,7 @@ SITE_OPS = {
     "F": (0, 0, _mat({(0, 0): 1, (1, 1): -1, (2, 2): 1})),          # fermion parity (JW string)
     "n": (0, 0, _mat({(1, 1): 1, (2, 2): 2})),                      # Number(), src:312-327
     "docc": (0, 0, _mat({(2, 2): 1})),                              # OSInteraction(), src:298-310
+    "nF": (0, 0, _mat({(1, 1): -1, (2, 2): 2})),                    # n F: the density inside a Jordan-Wigner string (U112 terms)
     "cdag": (1, +1, _mat({(1, 0): 1, (2, 1): -SQ2})),               # c+ closing a term
     "cdagF": (1, +1, _mat({(1, 0): 1, (2, 1): SQ2})),               # c+ opening a term (c+ F)
     "c": (1, -1, _mat({(0, 1): SQ2, (1, 2): 1})),                   # c  closing a term
@@ -394,11 +395,35 @@ def _charge_u1(m):
     return q.pop()
 
 
+def _string_entries_su2(sym, nsites, onsite, strings):
+    """SU(2) modes: strings = [(coef, [(site, reduced operator name)] in chain order, [(dN, 2k) of the level after each
+    operator but the last])]; sites between two operators pass the level through with F (odd dN) or the identity"""
+    ent, lvl = {}, {}
+    for idx, (coef, seq, labels) in enumerate(strings):
+        if coef == 0.0 or seq[0][0] < 0 or seq[-1][0] >= nsites:
+            continue
+        prev = ("start",)
+        for n_, (p, op) in enumerate(seq):
+            last = n_ == len(seq) - 1
+            cur = ("final",) if last else ("str", idx, p + 1)
+            ent.setdefault(p, []).append((prev, cur, op, coef if last else 1.0))
+            if not last:
+                lvl.setdefault(p + 1, []).append((cur, tuple(labels[n_])))
+                passop = "F" if labels[n_][0] % 2 else "id"
+                for q in range(p + 1, seq[n_ + 1][0]):           # sites in between
+                    nxt = ("str", idx, q + 1)
+                    ent.setdefault(q, []).append((cur, nxt, passop, 1.0))
+                    lvl.setdefault(q + 1, []).append((nxt, tuple(labels[n_])))
+                    cur = nxt
+            prev = cur
+    return sym, onsite, ent, lvl
+
+
 def _string_entries(sym, nsites, onsite, strings):
     """-> (symmetry with the strings' local matrices registered as site operators, onsite incl. one-site strings,
     {site: [(left level name, right level name, op, coef)]}, {bond: [(level name, label)]})"""
     if sym.kind != 1:
-        raise NotImplementedError("operator strings (U112 / U1111 terms) are available in the spinful mode (spin=true) only")
+        return _string_entries_su2(sym, nsites, onsite, strings)
     ops, names = dict(sym.site_ops), {}
 
     def opname(m):
@@ -580,6 +605,14 @@ def hamiltonian(sim: Simulation, L: int):
                             _assisted_hop(pairs, j, i, 0.5 * (M[bi, bf, 2] + M[bi, bf, 3]))      # density on i
         strings = []
         orb = lambda o, cell: site((o - 1) % B, cell + (o - 1) // B)                      # 1-based orbital over r B -> chain site
+
+        def reduced(tag, orbs, coef):
+            """SU(2) modes: the string(s) of hubbardtn_amd/string_table.py for this product and this order on the chain"""
+            from .string_table import TABLE
+            order = sorted(orbs)
+            perm = tuple(order.index(x) for x in orbs)
+            for (cf, names, labels) in TABLE[(tag, perm)]:
+                strings.append((coef * cf, list(zip(order, names)), labels))
         for name in ("U112", "U1111"):
             for key, U in (sim.kwargs.get(name) or {}).items():
                 i, j, k, l = (int(x) for x in key)
@@ -593,7 +626,17 @@ def hamiltonian(sim: Simulation, L: int):
                     o = lambda x: orb(x, cell)
                     if max(o(i), o(j), o(k), o(l)) >= n:
                         continue
-                    if name == "U1111":            # Uijkl, src:782-809: 0.5 U E_il E_jk (the dictionary holds every permutation)
+                    if name == "U112" and not (k == l or j == k or j == l):
+                        raise ValueError("U112: the repeated index must be k = l, j = k or j = l")
+                    if sym.kind != 1:              # SU(2) modes: reduced operator strings from the generated table
+                        if name == "U1111":
+                            reduced("abcd", (o(i), o(l), o(j), o(k)), 0.5 * U)
+                        else:
+                            tag, orbs, cf = (("kk", (o(i), o(j), o(k)), 0.5 * U) if k == l else
+                                             ("jk", (o(i), o(j), o(l)), U) if j == k else ("jl", (o(i), o(j), o(k)), 0.5 * U))
+                            reduced(tag, orbs, cf)
+                            reduced(tag + "+", orbs, cf)
+                    elif name == "U1111":          # Uijkl, src:782-809: 0.5 U E_il E_jk (the dictionary holds every permutation)
                         _hop_product(strings, 0.5 * U, o(i), o(l), o(j), o(k), herm=False)
                     elif k == l:                   # Uijkk, src:732-780: C1 + C1'
                         _hop_product(strings, 0.5 * U, o(j), o(k), o(i), o(k))
@@ -602,9 +645,7 @@ def hamiltonian(sim: Simulation, L: int):
                             nj = np.diag([0.0, 1.0, 1.0, 2.0])
                             strings.append((U, _jw_string([(o(i), X.T, True), (o(l), X, True), (o(j), nj, False)])))
                             strings.append((U, _jw_string([(o(j), nj, False), (o(l), X.T, True), (o(i), X, True)])))
-                    elif j == l:                   # C3 + C3'
+                    else:                          # j == l: C3 + C3'
                         _hop_product(strings, 0.5 * U, o(j), o(k), o(i), o(j))
-                    else:
-                        raise ValueError("U112: the repeated index must be k = l, j = k or j = l")
         return _build_mpo(n, onsite, pairs, sym, strings=strings)
     raise TypeError(f"unsupported simulation type {type(sim)}")

@@ -157,6 +157,7 @@ def site_operators():
     ops["F"] = (0, 0, reduce_site_operator([F], 0))
     ops["n"] = (0, 0, reduce_site_operator([lm["n"]], 0))
     ops["docc"] = (0, 0, reduce_site_operator([lm["docc"]], 0))
+    ops["nF"] = (0, 0, reduce_site_operator([lm["n"] @ F], 0))                  # the density inside a Jordan-Wigner string
     # creators: components (up, down)
     ops["cdag"] = (1, +1, reduce_site_operator([a_up.T, a_dn.T], 1))          # absorb side
     ops["cdagF"] = (1, +1, reduce_site_operator([a_up.T @ F, a_dn.T @ F], 1))  # emit side

@@ -203,3 +203,17 @@ def test_spinful_u1u1_mode_matches_exact_diagonalisation(hip_ops):
         for _ in range(4):
             Es[spin] = e.sweep()
     assert abs(Es[True] - Es[False]) < 1e-9 * abs(Es[False])
+
+
+def test_three_and_four_index_terms_match_the_oracle(hip_ops):
+    """U112 / U1111 of MB_Sim as reduced operator strings (hubbardtn_amd/string_table.py): MPO levels whose operators couple
+    two non-trivial spins go through the same compiled contractions -- the HIP engine against the numpy oracle (explicit
+    Clebsch-Gordan tensors) on the same MPO, truncated sweeps, energies and Schmidt spectra at 1e-8"""
+    tm = np.array([[0.1, 1.0, 0.3]])
+    um = np.array([[3.0, 0.5, 0.0]])
+    U1111 = {(1, 2, 3, 4): 0.31, (4, 3, 2, 1): 0.31, (1, 3, 4, 2): -0.2, (2, 4, 3, 1): -0.2, (1, 2, 4, 5): 0.15, (5, 4, 2, 1): 0.15}
+    U112 = {(1, 2, 3, 3): 0.25, (1, 3, 3, 4): -0.15, (2, 3, 1, 3): 0.1, (1, 5, 5, 2): 0.11}
+    L = 8
+    H = models.hamiltonian(models.MB_Sim(tm, um, np.zeros((1, 2)), 1, 1, 2.0, 8, U1111=U1111, U112=U112), L)
+    assert any(W.left[e[0]][1] and W.right[e[1]][1] and H.sym.site_ops[e[2]][0] for W in H for e in W.entries)   # a genuine mid-string entry
+    _generic_oracle_vs_hip(hip_ops, H, L, (L, 0), 40, 2, 5)

@@ -434,3 +434,64 @@ def test_merged_channel_mpo_is_the_same_operator_on_a_narrower_bond():
     # range-3 hopping alone: 3 levels per channel type instead of 6
     H3 = models.hamiltonian(models.OB_Sim([1.0, 0.3, 0.1], [4.0]), 10)
     assert len(H3[5].left) == 2 + 2 * 3
+
+
+def test_three_and_four_index_terms_as_reduced_operator_strings():
+    """U112 / U1111 of MB_Sim (Uijkk / Uijkl, src:732-809) in the SU(2) x U(1) mode: products of two spin-summed hoppings
+    become strings of reduced site operators with MPO levels of spin 0, 1/2 and 1 in between -- operators that couple two
+    non-trivial spins (hubbardtn_amd/string_table.py, generated and fitted exactly by tests/golden/make_string_table.py).
+    Pinned here: the reduced MPO, expanded with explicit Clebsch-Gordan tensors, equals the spinful mode's Jordan-Wigner
+    operator strings (pinned against second quantisation in tests/test_spinful_cpu.py) for orbitals in every relative
+    order, with gaps between them and across cells; and the C++ engine on that MPO finds the dense ground state of the
+    (N, S = 0) sector (mid-string entries: level spin x operator rank -> level spin, all three non-zero)."""
+    from oracle import su2
+    from cpu_ops import CpuOps
+    from test_spinful_cpu import _dense_from_abelian_mpo
+    from hubbardtn_amd import engine as cengine
+    B, cells = 1, 5                                        # one band: orbital o sits on chain site o - 1 (+ cell)
+    n = B * cells
+    tm = np.array([[0.1, 1.0, 0.3]])
+    um = np.array([[3.0, 0.5, 0.0]])
+    rng = np.random.default_rng(0)
+    U1111 = {key: float(rng.standard_normal()) for key in [(1, 2, 3, 4), (2, 4, 1, 3), (1, 3, 4, 2), (4, 1, 2, 3), (1, 4, 5, 2), (2, 5, 3, 1),
+                                                             (1, 2, 4, 5), (5, 1, 4, 2)]}
+    U112 = {(1, 2, 3, 3): 0.25, (1, 3, 3, 4): -0.15, (2, 3, 1, 3): 0.1, (3, 1, 4, 4): 0.3, (4, 2, 2, 1): -0.2, (3, 2, 1, 2): 0.17,
+            (1, 5, 5, 2): 0.11, (1, 3, 5, 3): -0.07, (4, 1, 1, 2): 0.21}
+    mk = lambda **kw: models.MB_Sim(tm, um, np.zeros((B, 2 * B)), 1, 1, 2.0, 8, **kw)
+    Ma = _dense_from_abelian_mpo(models.hamiltonian(mk(spin=True, U1111=U1111, U112=U112), cells))
+    Hs = models.hamiltonian(mk(U1111=U1111, U112=U112), cells)
+    Ms = ompo.mpo_to_dense(_as_dict(Hs))
+    assert np.abs(Ma - Ms).max() < 1e-12
+    # Hermitian part only for the eigenvalue check: the random U1111 above is not symmetrised (U[(i,j,k,l)] != U[(l,k,j,i)])
+    U1111h = {}
+    for (i, j, k, l), v in U1111.items():
+        U1111h[(i, j, k, l)] = U1111h.get((i, j, k, l), 0.0) + 0.5 * v
+        U1111h[(l, k, j, i)] = U1111h.get((l, k, j, i), 0.0) + 0.5 * v
+    H = models.hamiltonian(mk(U1111=U1111h, U112=U112), cells)
+    M = ompo.mpo_to_dense(_as_dict(H))
+    assert np.abs(M - M.T).max() < 1e-12
+    Nel = n - 1                                            # (an even electron number: the singlet sector exists)
+    bonds, tens = mps.random_mps(n, (Nel, 0), 64, seed=4)
+    eng = cengine.DMRG2(CpuOps(), H, bonds, tens, chi_full=None, lanczos_tol=1e-12)
+    for _ in range(4):
+        E0 = eng.sweep()
+    lm = su2.local_matrices()
+
+    def site_op(mats):
+        out = np.eye(1)
+        for s in range(n):
+            out = np.kron(out, mats.get(s, lm["id"]))
+        return out
+
+    def c_op(i, spin):
+        mats = {s: lm["F"] for s in range(i)}
+        mats[i] = lm["a_up"] if spin == 0 else lm["a_dn"]
+        return site_op(mats)
+    c = {(i, s): c_op(i, s) for i in range(n) for s in (0, 1)}
+    Ntot = sum(c[k].T @ c[k] for k in c)
+    Sp = sum(c[(i, 0)].T @ c[(i, 1)] for i in range(n))
+    Sz = 0.5 * sum(c[(i, 0)].T @ c[(i, 0)] - c[(i, 1)].T @ c[(i, 1)] for i in range(n))
+    S2 = Sp @ Sp.T + Sz @ Sz - Sz
+    Id = np.eye(4 ** n)
+    w = np.linalg.eigvalsh(M + 50.0 * (Ntot - Nel * Id) @ (Ntot - Nel * Id) + 50.0 * S2)
+    assert abs(E0 - w[0]) < 1e-9 * max(abs(w[0]), 1.0)

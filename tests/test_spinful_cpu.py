@@ -197,8 +197,7 @@ def test_three_and_four_index_terms_in_the_spinful_mode(cpu_ops):
     """U112 / U1111 of MB_Sim (Uijkk / Uijkl, src:732-809): products of two spin-summed hoppings E_ab = sum_s c+_{a s} c_{b s}
     -- 0.5 U E_il E_jk (four different orbitals), 0.5 U (E_jk E_ik + h.c.), U (E_il n_j + h.c.), 0.5 U (E_jk E_ij + h.c.)
     (two equal) -- built as Jordan-Wigner operator strings in the fZ2 x U(1) x U(1) mode (models._jw_string): the MPO equals
-    the dense second-quantised operator exactly, the engine finds the dense ground state of the (N, Sz = 0) sector, and
-    the SU(2) mode refuses.  (Upstream never switches these terms on in its tests; the operator order inside the reference's
+    the dense second-quantised operator exactly, the engine finds the dense ground state of the (N, Sz = 0) sector.  (Upstream never switches these terms on in its tests; the operator order inside the reference's
     @tensor contractions is unverifiable here: parity unpinned.)"""
     from oracle import su2
     B, cells = 2, 2
@@ -252,7 +251,5 @@ def test_three_and_four_index_terms_in_the_spinful_mode(cpu_ops):
     keep = np.nonzero((np.abs(diag(np.array([0.0, 1.0, 1.0, 2.0])) - n) < 1e-9) & (np.abs(diag(np.array([0.0, 0.5, -0.5, 0.0]))) < 1e-9))[0]
     w = np.linalg.eigvalsh(M[np.ix_(keep, keep)])
     assert abs(E0 - w[0]) < 1e-9 * max(abs(w[0]), 1.0)
-    with pytest.raises(NotImplementedError, match="spinful"):
-        models.hamiltonian(mk(U1111=U1111), cells)
     with pytest.raises(ValueError, match="site 0"):
         models.hamiltonian(mk(spin=True, U1111={(3, 4, 5, 6): 1.0}), cells)
