@@ -366,7 +366,81 @@ def _build_mpo(nsites, onsite, pairs, sym=None, merge=True, strings=()):
             if s in closings:
                 ent.append((il[name], ir[("final",)], op_close, closings[s]))
         sites.append(MPOSite(ql, qr, ent))
-    return MPO(sites, sym)
+    H = MPO(sites, sym)
+    return _compress_mpo(H) if merge else H
+
+
+def _compress_mpo(H, tol=1e-14):
+    """Exact compression of the finite-state-machine MPO by deparallelisation (no SVD, the operator is unchanged): two
+    levels of a bond with the same label whose FUTURES are proportional -- the same (right level, operator) entries on the
+    next site up to one common factor -- are one level (the entries arriving at the second are redirected to the first,
+    scaled); likewise two levels whose PASTS are proportional.  Swept right-to-left, then left-to-right, until nothing
+    changes.  The start / final levels are never merged.  Typical effect: operator strings that share a suffix or a
+    prefix (the U112 / U1111 terms, exchange channels of several ranges) share their levels; the plain hopping chain is
+    already minimal.  ("prune zero-weight terms and compress the MPO"; the reference does neither.)"""
+    sites = [MPOSite(list(W.left), list(W.right), [e for e in W.entries if e[3] != 0.0]) for W in H]
+    n = len(sites)
+
+    def merge_bond(b, futures):
+        """merge proportional levels of bond b (between site b-1 and site b); futures=True compares outgoing entries"""
+        W_in, W_out = sites[b - 1], sites[b]
+        labels = W_out.left
+        nlev = len(labels)
+        sig = {}
+        for w in range(nlev):
+            ents = ([(e[1], e[2], e[3]) for e in W_out.entries if e[0] == w] if futures else
+                    [(e[0], e[2], e[3]) for e in W_in.entries if e[1] == w])
+            ents.sort(key=lambda t: (t[0], t[1]))
+            sig[w] = ents
+        keep, scale = {}, {}
+        changed = False
+        for w in range(1, nlev - 1):                     # level 0 = start, last = final
+            if not sig[w]:
+                continue
+            f0 = sig[w][0][2]
+            key = (labels[w], tuple((x, op, round(c / f0, 12)) for (x, op, c) in sig[w]))
+            if key in keep:
+                scale[w] = (keep[key][0], f0 / keep[key][1])      # w = factor * representative
+                changed = True
+            else:
+                keep[key] = (w, f0)
+        if not changed:
+            return False
+        dead = set(scale)
+        remap, k = {}, 0
+        for w in range(nlev):
+            if w not in dead:
+                remap[w] = k
+                k += 1
+        newlab = [labels[w] for w in range(nlev) if w not in dead]
+
+        def fix(entries, side):
+            acc = {}
+            for (wl, wr, op, c) in entries:
+                w = wl if side == 0 else wr
+                if w in dead:
+                    if (futures and side == 0) or (not futures and side == 1):
+                        continue                             # the merged level's own outgoing (incoming) entries disappear
+                    rep, f = scale[w]
+                    w, c = rep, c * f
+                w = remap[w]
+                key = (w, wr, op) if side == 0 else (wl, w, op)
+                acc[key] = acc.get(key, 0.0) + c
+            return [(a, b_, op, c) for (a, b_, op), c in acc.items() if abs(c) > tol]
+        W_in.entries = fix(W_in.entries, 1)
+        W_out.entries = fix(W_out.entries, 0)
+        W_in.right = list(newlab)
+        W_out.left = list(newlab)
+        return True
+    for _ in range(8):
+        any_change = False
+        for b in range(n - 1, 0, -1):
+            any_change |= merge_bond(b, True)
+        for b in range(1, n):
+            any_change |= merge_bond(b, False)
+        if not any_change:
+            break
+    return MPO(sites, H.sym)
 
 
 def _jw_string(ops):

@@ -495,3 +495,34 @@ def test_three_and_four_index_terms_as_reduced_operator_strings():
     Id = np.eye(4 ** n)
     w = np.linalg.eigvalsh(M + 50.0 * (Ntot - Nel * Id) @ (Ntot - Nel * Id) + 50.0 * S2)
     assert abs(E0 - w[0]) < 1e-9 * max(abs(w[0]), 1.0)
+
+
+def test_mpo_compression_keeps_the_operator_and_narrows_the_bond():
+    """models._compress_mpo (exact deparallelisation: levels with proportional futures or pasts are one level): the dense
+    operator is unchanged to rounding; the plain hopping chain is already minimal in the bulk; operator strings that share
+    prefixes / suffixes (U112 / U1111) lose more than half of their levels; level labels stay consistent (every entry
+    connects labels the operator's charge allows)"""
+    def both(sim, L):
+        H = models.hamiltonian(sim, L)
+        keep = models._compress_mpo
+        models._compress_mpo = lambda H_: H_
+        try:
+            H0 = models.hamiltonian(sim, L)
+        finally:
+            models._compress_mpo = keep
+        return H0, H
+    H0, H = both(models.OB_Sim([1.0], [4.0]), 6)
+    assert [len(W.left) for W in H] == [len(W.left) for W in H0] == [1, 4, 4, 4, 4, 4]
+    H0, H = both(models.OB_Sim([1.0, 0.3, 0.1], [4.0, 0.5, 0.2], 0.1, [0.3, 0.1], 1, 1), 6)
+    assert np.abs(ompo.mpo_to_dense(_as_dict(H)) - ompo.mpo_to_dense(_as_dict(H0))).max() < 1e-13
+    assert [len(W.left) for W in H][2:5] == [len(W.left) for W in H0][2:5]              # bulk untouched, edges pruned
+    tm, um = np.array([[0.1, 1.0, 0.3]]), np.array([[3.0, 0.5, 0.0]])
+    U1111 = {(1, 2, 3, 4): 0.31, (4, 3, 2, 1): 0.31, (1, 3, 4, 2): -0.2, (2, 4, 3, 1): -0.2, (1, 2, 4, 5): 0.15, (5, 4, 2, 1): 0.15}
+    U112 = {(1, 2, 3, 3): 0.25, (1, 3, 3, 4): -0.15, (2, 3, 1, 3): 0.1, (1, 5, 5, 2): 0.11}
+    H0, H = both(models.MB_Sim(tm, um, np.zeros((1, 2)), 1, 1, 2.0, 8, U1111=U1111, U112=U112), 6)
+    assert np.abs(ompo.mpo_to_dense(_as_dict(H)) - ompo.mpo_to_dense(_as_dict(H0))).max() < 1e-13
+    assert 2 * max(len(W.left) for W in H) < max(len(W.left) for W in H0)
+    for W in H:
+        for (wl, wr, op, c) in W.entries:
+            k, dN, _ = H.sym.site_ops[op]
+            assert W.right[wr][0] == W.left[wl][0] + dN and abs(W.left[wl][1] - k) <= W.right[wr][1] <= W.left[wl][1] + k
