@@ -342,8 +342,8 @@ def double_occupancy(psi):
 def TruncState(simul: Simulation, trunc_dim: int, trunc_scheme: int = 0, L: int | None = None, **kw):
     """truncated approximation of the ground state at bond dimension `trunc_dim` (TensorKit dim units), src:1351-1367.
     trunc_scheme 1 = SvdCut (truncate by SVD only); 0 = VUMPSSvdCut (truncate, then re-optimise variationally at
-    that dimension -- here: further two-site sweeps with truncdim(trunc_dim)).  Finite chains (L given); for the
-    infinite chain scheme 0 = IDMRG2 at truncdim(trunc_dim)."""
+    that dimension -- here: further two-site sweeps with truncdim(trunc_dim)).  Finite chains (L given) and the infinite
+    chain: scheme 1 cuts the bonds of the converged window, scheme 0 = IDMRG2 at truncdim(trunc_dim)."""
     if trunc_dim <= 0:
         raise ValueError("trunc_dim should be a positive integer.")
     if trunc_scheme not in (0, 1):
@@ -351,7 +351,18 @@ def TruncState(simul: Simulation, trunc_dim: int, trunc_scheme: int = 0, L: int 
     L = L or simul.kwargs.get("L")
     if L is None:
         if trunc_scheme == 1:
-            raise NotImplementedError("SvdCut of an infinite MPS needs the uniform gauge (not on the hot path)")
+            # SvdCut of the infinite state (test/MB.jl:95-103): every bond inside the converged window -- two unit cells between
+            # the environments of the half-infinite blocks -- is cut to truncdim(trunc_dim) by its own Schmidt decomposition,
+            # without re-optimisation; the energy density moves by the window's energy change per site
+            d = compute_groundstate(simul, **kw)
+            psi = d["groundstate"]
+            r, eng = psi.result, psi.result.engine
+            E_before, _ = eng.bond_energies()
+            E_after = eng.svd_cut(trunc_dim)
+            r.bond_dims = eng.bond_dims()
+            r.energy_per_site += (E_after - E_before) / eng.L
+            r.spectrum = eng.spectrum(r.unit_cell)
+            return {"ψ_trunc": psi, "envs_trunc": Environments(eng)}
         d = compute_groundstate(simul, chi=trunc_dim, **kw)
         return {"ψ_trunc": d["groundstate"], "envs_trunc": d["environments"]}
     d = produce_groundstate(simul, L=L, **kw)

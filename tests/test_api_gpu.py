@@ -1,9 +1,14 @@
 """the reference's call sequence (examples/One_band.jl:20-46) through hubbardtn_amd.api on the GPU"""
+import json
+import os
+
 import numpy as np
 import pytest
 
 from hubbardtn_amd import api
 from oracle import ed
+
+GOLD_MB = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_constants.json")))["MB_groundstate"]
 
 pytestmark = pytest.mark.gpu
 
@@ -83,3 +88,20 @@ def test_truncstate_schemes():
         E[scheme] = float(np.sum(api.expectation_value(psi, None)))
     assert Eref - 1e-9 <= E[0] <= E[1] + 1e-12
     assert E[1] - Eref < 5e-3 and E[0] - Eref < 2e-3
+
+
+def test_truncstate_svdcut_of_the_infinite_chain():
+    """test/MB.jl:95-103: `produce_TruncState(model, 5; trunc_scheme=1)` on the infinite two-band chain, then
+    `sum(dim_state(psi_trunc)) / 4 <= trunc_dim` and the filling check of the truncated state"""
+    rec = GOLD_MB
+    model = api.MB_Sim(np.array(rec["t"]), np.array(rec["u"]), np.array(rec["J"]), rec["P"], rec["Q"], rec["svalue"], rec["bond_dim"])
+    d = api.produce_groundstate(model, tol=1e-4, maxiter=30)
+    D = api.dim_state(d["groundstate"])
+    assert len(D) == 4 and min(D) > 0 and max(D) > 5
+    dt = api.produce_TruncState(model, 5, trunc_scheme=1, tol=1e-4, maxiter=30)
+    Dt = api.dim_state(dt["ψ_trunc"])
+    assert len(Dt) == 4 and min(Dt) > 0 and sum(Dt) / 4 <= 5 and max(Dt) <= 5
+    n = api.density_state(dt["ψ_trunc"])
+    assert abs(float(np.sum(n)) / 4 - rec["P"] / rec["Q"]) < 1e-8
+    # the cut costs energy: the truncated state's energy density lies above the converged one
+    assert dt["ψ_trunc"].result.energy_per_site > d["groundstate"].result.energy_per_site
