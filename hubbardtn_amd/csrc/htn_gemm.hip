@@ -165,10 +165,11 @@ extern "C" int htn_gemm_prof_dump(long long* out, int n) {
 }
 #endif
 #ifndef GEMM_DEPTH
-#define GEMM_DEPTH 2     // K slabs in registers per wave (32 VGPRs each)
+#define GEMM_DEPTH 1     // K slabs in registers per wave (32 VGPRs each).  Measured: 1 slab x 6 resident workgroups per CU
+                         // beats 2 x 4 by 5 % at chi = 1024 (latency is hidden across waves rather than inside one)
 #endif
 #ifndef GEMM_MINOCC
-#define GEMM_MINOCC 4     // workgroups (one wave per SIMD each) co-resident per CU
+#define GEMM_MINOCC 6     // workgroups (one wave per SIMD each) co-resident per CU
 #endif
 __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_MINOCC) void k_grouped_gemm_z(BufTable bufs, const htn_tile* __restrict__ tiles,
                                                                        const htn_seg* __restrict__ segs) {

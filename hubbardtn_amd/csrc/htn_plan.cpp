@@ -509,7 +509,7 @@ inline Key tkey(Sec a, int s1, Sec c, int s2, Sec b) { return mk(a.N, a.j, s1, c
 //      one more part, longest part to the least loaded CU -- preferably a CU of the XCD where the part's output strip
 //      already lives (operands then come out of that XCD's L2); GEMM_RESIDENT layers are co-resident (occupancy);
 //   3. whatever does not fit those layers follows longest first: it is dispatched dynamically as slots free up.
-#define GEMM_RESIDENT 4      // workgroups of k_grouped_gemm_z co-resident per CU (its launch bounds: 4 waves per SIMD)
+#define GEMM_RESIDENT 6      // workgroups of k_grouped_gemm_z co-resident per CU (its launch bounds: 6 waves per SIMD)
 int balance_tiles(Tasks& t, int n_cus) {
     const int nt = t.ntiles;
     if (nt <= 0) return 0;
