@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
@@ -77,24 +79,27 @@ dist.destroy_process_group()
 '''
 
 
-def test_cxx_engine_sharded_apply_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_cxx_engine_sharded_apply_two_ranks_gloo(tmp_path, world):
     """the product's C++ sweep driver with the sector-parallel apply (tiles dealt over ranks inside the library, y
     zero-filled, ONE reduction per matvec through the exchange hook) and the sector-sharded SVD (every rank decomposes
-    the blocks it owns, two reductions per bond hand everybody the complete result) at world size 2 over gloo: ranks stay
-    in lock step bit for bit and reproduce the unsharded golden energies and spectra"""
+    the blocks it owns, two reductions per bond hand everybody the complete result) at world size 2 and 3 (an odd deal of
+    tiles and blocks) over gloo: ranks stay in lock step bit for bit and reproduce the unsharded golden energies and spectra"""
     script = tmp_path / "worker_cxx.py"
     script.write_text(WORKER_CXX)
     env = dict(os.environ, HTN_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29543", str(script)],
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29541 + world), str(script)],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)["out"]
-    (E0, S0, c0, mv0), (E1, S1, c1, mv1) = res
-    assert E0 == E1 and S0 == S1                              # lock step, bit for bit
-    # exactly one reduction per matvec, plus two per bond update for the sector-sharded SVD (blocks, singular values)
-    assert c0 == c1 == mv0 == mv1 and c0 > 0
+    assert len(res) == world
+    (E0, S0, c0, mv0) = res[0]
+    for (E1, S1, c1, mv1) in res[1:]:
+        assert E0 == E1 and S0 == S1                          # lock step, bit for bit
+        # exactly one reduction per matvec, plus two per bond update for the sector-sharded SVD (blocks, singular values)
+        assert c0 == c1 == mv0 == mv1 and c0 > 0
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_r01.json")))["oracle_runs"]["L8_U4_chi64"]
     for a, b in zip(E0, gold["energies"]):
         assert abs(a - b) <= 1e-10 * abs(b)
