@@ -63,7 +63,13 @@ struct HipBackend : htn::Backend {
     int device = 0;
     hipStream_t st = nullptr;
     bool own_stream = false;
-    std::multimap<size_t, void*> free_list;       // size -> block (stream-ordered reuse: ONE stream does all the work)
+    // size -> block.  Reuse is STREAM ORDERED: a block released while kernels that use it are still queued may be handed out
+    // again at once, because whatever touches it next is enqueued behind them on the SAME stream `st`.  Invariant that makes
+    // this sound: every piece of device work of this backend is either on `st`, or on the SVD's forked stream between a
+    // fork event recorded on `st` and a join event `st` waits for before htn_jacobi_svd_z returns -- and no block is
+    // allocated or released while that fork is open (`fork_open`, asserted in alloc / release).
+    std::multimap<size_t, void*> free_list;
+    bool fork_open = false;
     std::map<void*, size_t> live;
     size_t pooled = 0;
     void* lan_scratch = nullptr;
@@ -78,6 +84,8 @@ struct HipBackend : htn::Backend {
     ~HipBackend() override {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
+        htn_krylov_release_stream(st);                // the Lanczos / SVD drivers' per-stream scratch, events, forked stream
+        htn_svd_release_stream(st);
         if (comm && rccl().ok) rccl().CommDestroy(comm);
         for (auto& kv : free_list) (void)hipFree(kv.second);
         for (auto& kv : live) (void)hipFree(kv.first);
@@ -87,8 +95,29 @@ struct HipBackend : htn::Backend {
         if (own_stream && st) (void)hipStreamDestroy(st);
     }
     int kind() const override { return HTN_BACKEND_HIP; }
+    // every ABI entry point that reaches the device goes through here first: allocations, events and launches of this
+    // context belong to ITS device whatever the calling thread's current device was
+    int activate() override {
+        HIP_TRY(hipSetDevice(device));
+        return 0;
+    }
 
+    // HTN_DEBUG_POISON: every block handed out is filled with 0xFF (NaN) first, stream ordered like its first use
+    void* poisoned(void* p, size_t bytes) {
+        if (p && htn_debug_poison() && hipMemsetAsync(p, 0xFF, bytes, st) != hipSuccess) {
+            (void)hipGetLastError();
+            htn::set_error("HTN_DEBUG_POISON: hipMemsetAsync failed");
+            live.erase(p);
+            (void)hipFree(p);
+            return nullptr;
+        }
+        return p;
+    }
     void* alloc(size_t bytes) override {
+        if (fork_open) {
+            htn::set_error("pool invariant violated: allocation while the SVD's forked stream is open");
+            return nullptr;
+        }
         bytes = (bytes + 255) / 256 * 256;
         // best fit within 25 %: per-bond buffers recur with slightly different sizes as the sector tables move
         auto it = free_list.lower_bound(bytes);
@@ -97,7 +126,7 @@ struct HipBackend : htn::Backend {
             live[p] = it->first;
             pooled -= it->first;
             free_list.erase(it);
-            return p;
+            return poisoned(p, live[p]);
         }
         void* p = nullptr;
         const size_t want = bytes + bytes / 8;       // headroom so that the next, slightly larger request still fits
@@ -113,12 +142,16 @@ struct HipBackend : htn::Backend {
                 return nullptr;
             }
             live[p] = bytes;
-            return p;
+            return poisoned(p, bytes);
         }
         live[p] = want;
-        return p;
+        return poisoned(p, want);
     }
     void release(void* p) override {
+        if (fork_open) {                              // (cannot fail: record it, the next alloc reports)
+            htn::set_error("pool invariant violated: release while the SVD's forked stream is open");
+            abort();
+        }
         auto it = live.find(p);
         if (it == live.end()) return;
         const size_t sz = it->second;
@@ -165,7 +198,7 @@ struct HipBackend : htn::Backend {
             return 0;
         }
         if (!land) {
-            HIP_TRY(hipHostMalloc((void**)&land, land_cap, hipHostMallocMapped));
+            HIP_TRY(hipHostMalloc((void**)&land, land_cap, hipHostMallocMapped | hipHostMallocCoherent));
             HIP_TRY(hipHostGetDevicePointer((void**)&land_dev, land, 0));
         }
         if (bytes <= ((size_t)256 << 10) && ((uintptr_t)src & 3) == 0) {        // (device blocks are 256-byte granular: the
@@ -200,6 +233,7 @@ struct HipBackend : htn::Backend {
         if (need > lan_scratch_elems) {
             if (lan_scratch) HIP_TRY(hipFree(lan_scratch));
             HIP_TRY(hipMalloc(&lan_scratch, sizeof(double2) * need));
+            if (htn_debug_poison()) HIP_TRY(hipMemsetAsync(lan_scratch, 0xFF, sizeof(double2) * need, st));
             lan_scratch_elems = need;
         }
         int32_t nmv = 0;
@@ -210,7 +244,10 @@ struct HipBackend : htn::Backend {
     }
     int jacobi_svd(void* G, void* Vj, double* S, const htn_svd_block* desc_dev, const htn_svd_block* desc_host, int n_blocks,
                    int max_m, int max_sweeps, double tol, int32_t* info_dev, const htn_svd_opts* opts) override {
-        return htn_jacobi_svd_z(G, Vj, S, desc_dev, desc_host, n_blocks, max_m, max_sweeps, tol, info_dev, opts, st);
+        fork_open = true;          // the call forks a second stream and joins it into `st` before it returns
+        const int rc = htn_jacobi_svd_z(G, Vj, S, desc_dev, desc_host, n_blocks, max_m, max_sweeps, tol, info_dev, opts, st);
+        fork_open = false;
+        return rc;
     }
     int batched_copy(void* dst, const void* src, const int32_t* idx, const double* scl, const htn_copy_item* items, int n_items,
                      double gscale) override {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "hubbardtn_hip.h"
@@ -46,6 +47,30 @@ static inline hipError_t htn_stream_spin(hipStream_t st) {
     return htn_event_spin(evs[dev]);
 }
 
+
+// ---- debug switches (test infrastructure; read once per process from the environment) ----------------------------------
+//   HTN_DEBUG_POISON=1       HipBackend::alloc fills every block it hands out with 0xFF bytes (NaN as doubles, -1 as
+//                            integers): one run exposes any kernel that consumes memory nobody wrote.
+//   HTN_DEBUG_EVENT_WAITS=1  every host wait on device results is a completed HIP event (hipEventSynchronize) instead of a
+//                            poll of host-mapped memory; the polled record is still validated.
+static inline bool htn_env_flag(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] && v[0] != '0';
+}
+static inline bool htn_debug_poison() {
+    static const bool on = htn_env_flag("HTN_DEBUG_POISON");
+    return on;
+}
+static inline bool htn_debug_event_waits() {
+    static const bool on = htn_env_flag("HTN_DEBUG_EVENT_WAITS");
+    return on;
+}
+
+// per-stream scratch of the multi-launch drivers (htn_krylov.hip, htn_svd.hip): owned by the stream's registry entry,
+// released by the backend that owns the stream (HipBackend::~HipBackend) -- nothing thread-local, nothing shared between
+// two contexts.  A caller of the kernel-level ABI that brings its own stream keeps its entry until the process ends.
+void htn_krylov_release_stream(hipStream_t st);
+void htn_svd_release_stream(hipStream_t st);
 
 // ---- cross-lane sums -------------------------------------------------------------------------------
 // Within a row of 16 lanes the butterfly runs on DPP (pure VALU, no LDS crossbar round trip):

@@ -271,6 +271,7 @@ void plan_finalize(const ThetaLayout& tl, const SvdPlan& sp, const std::vector<i
 struct Backend {
     virtual ~Backend() {}
     virtual int kind() const = 0;
+    virtual int activate() { return 0; }                 // make this backend's device current for the calling thread
     virtual void* alloc(size_t bytes) = 0;               // device memory, reuse is stream ordered; nullptr on failure
     virtual void release(void* p) = 0;
     virtual int upload(void* dst, const void* src_host, size_t bytes) = 0;      // source staged before return

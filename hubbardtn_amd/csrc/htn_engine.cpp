@@ -629,6 +629,7 @@ int htn_ctx_set_timing(htn_ctx* ctx, int32_t on) {
 }
 int htn_ctx_set_comm(htn_ctx* ctx, int32_t rank, int32_t world, const void* id_host) {
     if (world < 1 || rank < 0 || rank >= world) return set_error("htn_ctx_set_comm: bad rank %d / world %d", rank, world);
+    if (ctx->be->activate()) return 1;
     if (ctx->be->set_comm(rank, world, id_host)) return 1;
     ctx->rank = rank;
     ctx->world = world;
@@ -707,6 +708,7 @@ int htn_mps_create(htn_ctx* ctx, const htn_mpo* mpo, int32_t nsites, const int32
                    const void* left_env_host, const void* right_env_host, htn_mps** out) {
     if (!ctx || !mpo || !out) return set_error("htn_mps_create: NULL argument");
     if (nsites != (int)mpo->mpo.sites.size()) return set_error("htn_mps_create: %d sites but the MPO has %d", nsites, (int)mpo->mpo.sites.size());
+    if (ctx->be->activate()) return 1;
     // (errors below return through the guard: it drops the references the half-built object took)
     struct Guard {
         htn_mps* p;
@@ -779,6 +781,7 @@ void htn_mps_destroy(htn_mps* mps) {
     if (!mps) return;
     htn_ctx* c = mps->ctx;
     htn_mpo* m = mps->mpo_handle;
+    if (mps->be) (void)mps->be->activate();
     delete mps;              // device buffers go back to the backend's pool first ...
     mpo_release(m);          // ... then the references that kept the backend alive
     ctx_release(c);
@@ -804,9 +807,11 @@ static htn_sweep_opts norm_opts(const htn_sweep_opts* o) {
 
 int htn_bond_update(htn_mps* mps, int32_t i, int32_t direction, int32_t placement, int32_t optimise, const htn_sweep_opts* opts,
                     htn_bond_stats* stats) {
+    if (mps->be->activate()) return 1;
     return mps->update_bond(i, direction, placement == 0, optimise != 0, norm_opts(opts), stats);
 }
 int htn_dmrg2_sweep(htn_mps* mps, const htn_sweep_opts* opts, htn_bond_stats* stats, double* energy) {
+    if (mps->be->activate()) return 1;
     return mps->sweep(norm_opts(opts), stats, energy);
 }
 
@@ -816,6 +821,7 @@ int64_t htn_mps_theta_size(htn_mps* mps, int32_t i) {
 }
 int htn_mps_get_theta(htn_mps* mps, int32_t i, void* theta_host) {
     if (i < 0 || i + 1 >= mps->L) return set_error("htn_mps_get_theta: bond out of range");
+    if (mps->be->activate()) return 1;
     ThetaLayoutP tl = mps->theta_layout(mps->bonds[i], mps->bonds[i + 2]);
     DView t = mps->zalloc(tl->size, false);
     if (!t.base) return set_error("device allocation failed");
@@ -824,6 +830,7 @@ int htn_mps_get_theta(htn_mps* mps, int32_t i, void* theta_host) {
 }
 int htn_heff2_apply(htn_mps* mps, int32_t i, const void* x_host, void* y_host) {
     if (i < 0 || i + 1 >= mps->L) return set_error("htn_heff2_apply: bond out of range");
+    if (mps->be->activate()) return 1;
     ThetaLayoutP tl = mps->theta_layout(mps->bonds[i], mps->bonds[i + 2]);
     auto ap = mps->make_apply(i, *tl);
     if (!ap) return 1;
@@ -871,6 +878,7 @@ int32_t htn_mps_get_site(const htn_mps* mps, int32_t i, htn_subblock* subs, void
             const Key& k = lay.bkeys[q];
             subs[q] = {k[0], k[1], k[2], k[3], k[4], lay.blocks[q].ld, lay.blocks[q].off};
         }
+    if (data_host && lay.size && mps->be->activate()) return -1;
     if (data_host && lay.size && mps->be->download(data_host, mps->site_buf[i].ptr(), sizeof(cplx) * lay.size)) return -1;
     return (int32_t)lay.blocks.size();
 }
@@ -884,6 +892,7 @@ int htn_mps_get_env(const htn_mps* mps, int32_t side, int32_t b, void* data_host
     const EnvLayoutP& l = side == 0 ? mps->Llay[b] : mps->Rlay[b];
     if (!l) return set_error("htn_mps_get_env: environment %d of bond %d does not exist yet", side, b);
     if (l->size == 0) return 0;
+    if (mps->be->activate()) return 1;
     return mps->be->download(data_host, (side == 0 ? mps->Lbuf[b] : mps->Rbuf[b]).ptr(), sizeof(cplx) * l->size);
 }
 int32_t htn_mps_env_bond(const htn_mps* mps, int32_t side, int32_t b, htn_sector* out) {

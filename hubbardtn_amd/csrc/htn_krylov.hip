@@ -10,6 +10,9 @@
 // 64 partials with a butterfly), so results are bit-reproducible run to run and rank to rank.
 #include <math.h>
 
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "htn_common.h"
@@ -85,7 +88,7 @@ __global__ void k_dots_reduce(const double2* __restrict__ partial, int nvec, dou
 }
 
 // fused: c = reduce(partial); w += sign * V c ; norm_partial[b] = |w_new slice|^2 ; block 0 writes c[c_index]
-// to *c_out (host-pinned memory: the Lanczos driver reads <v_j, w> from a slot private to its step)
+// to *c_out (a device scalar: the step's last kernel, k_scale_by_norm, hands it to the host inside the step record)
 __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__ w, const double2* __restrict__ V,
                                                            int64_t ldv, int nvec,
                                                            const double2* __restrict__ partial,
@@ -225,10 +228,28 @@ static void launch_axpy_dots(double2* w, const double2* V, int64_t ldv, int nvec
 #undef HTN_AD
 }
 
-// dst = src / sqrt(sum norm_partial); block 0 writes the squared norm to nrm2_out (may be null)
+// Step record handed to the host, one 32-byte slot per Lanczos step in host-mapped COHERENT pinned memory.  It is written
+// by ONE lane of the step's LAST kernel as two 16-byte stores and validates itself: word 3 = serial ^ mix(words 0..2),
+// where `serial` is a number the host chose for exactly this step and never reuses.  The host accepts a slot only when
+// the check reproduces the serial it expects, so neither a slot left over from an earlier solve, nor a half-arrived
+// record, nor any reordering of the two stores on their way to host memory can be taken for the step's result; and
+// the CPU never writes into this block (no sentinel), so no CPU store can share a cache line with a device store.
+struct LanRecord {
+    unsigned long long w[4];      // bits of <v_j,w> pass 1 (re), pass 2 (re), |w|^2 after orthogonalisation, check
+};
+__host__ __device__ __forceinline__ unsigned long long lan_rotl(unsigned long long x, int r) { return (x << r) | (x >> (64 - r)); }
+__host__ __device__ __forceinline__ unsigned long long lan_check(unsigned long long w0, unsigned long long w1, unsigned long long w2,
+                                                                 unsigned long long serial) {
+    return serial ^ lan_rotl(w0, 13) ^ lan_rotl(w1, 29) ^ lan_rotl(w2, 47) ^ 0x9E3779B97F4A7C15ull;
+}
+
+// dst = src / sqrt(sum norm_partial); with rec_out, block 0 publishes the step record {c1[0].re, c2[0].re, |w|^2}
+// (c1 / c2: device scalars written by the EARLIER kernels of the step -- same stream, hence complete and visible)
 __global__ __launch_bounds__(DOT_THREADS) void k_scale_by_norm(double2* __restrict__ dst, const double2* __restrict__ src,
                                                                const double* __restrict__ norm_partial, int64_t n,
-                                                               double* __restrict__ nrm2_out) {
+                                                               LanRecord* __restrict__ rec_out,
+                                                               const double2* __restrict__ c1, const double2* __restrict__ c2,
+                                                               unsigned long long serial) {
     __shared__ double s_inv;
     const int tid = threadIdx.x;
     if (tid < 64) {
@@ -238,8 +259,13 @@ __global__ __launch_bounds__(DOT_THREADS) void k_scale_by_norm(double2* __restri
         t = wave_sum(t);
         if (tid == 0) {
             s_inv = t > 0.0 ? 1.0 / sqrt(t) : 0.0;
-            if (blockIdx.x == 0 && nrm2_out) {
-                nrm2_out[0] = t;                 // host-pinned slot: the Lanczos driver polls it (no event marker per step)
+            if (blockIdx.x == 0 && rec_out) {
+                const unsigned long long w0 = (unsigned long long)__double_as_longlong(c1[0].x);
+                const unsigned long long w1 = (unsigned long long)__double_as_longlong(c2[0].x);
+                const unsigned long long w2 = (unsigned long long)__double_as_longlong(t);
+                ulonglong2* out = (ulonglong2*)rec_out;
+                out[0] = make_ulonglong2(w0, w1);
+                out[1] = make_ulonglong2(w2, lan_check(w0, w1, w2, serial));
                 __threadfence_system();
             }
         }
@@ -403,8 +429,63 @@ static void tridiag_lowest(const std::vector<double>& alpha, const std::vector<d
 }
 
 extern "C" int64_t htn_lanczos_scratch_elems(int32_t krylovdim) {
-    // 2 x partial sums (krylovdim+1 vectors) + c1 + c2 + y (each krylovdim+1) + norm partials / nrm2 (as doubles)
+    // 2 x partial sums (krylovdim+1 vectors) + c1 + c2 + y (each krylovdim+1) + norm partials (as doubles)
     return 2 * (int64_t)(krylovdim + 1) * DOT_BLOCKS + 3 * (krylovdim + 1) + DOT_BLOCKS + 8;
+}
+
+// ---- per-stream resources of the driver (htn_common.h: owned by the stream's registry entry) ----------------------------
+#define LAN_SLOTS 64
+namespace {
+struct LanRes {
+    int device = -1;
+    LanRecord* h_rec = nullptr;      // [LAN_SLOTS] host view  \ hipHostMallocMapped | hipHostMallocCoherent: written by the
+    LanRecord* d_rec = nullptr;      //             device view / device only, read by the host only
+    double2* h_y = nullptr;          // Ritz coefficients, host -> device staging (a SEPARATE allocation)
+    hipEvent_t ev_done[LAN_SLOTS], ev_mv0[LAN_SLOTS], ev_mv1[LAN_SLOTS];
+    bool have_events = false;
+    unsigned long long serial = 0;   // last step serial handed out; never reused within the life of the entry
+    unsigned sample = 0;             // phase of the 1-in-8 matvec timing sample
+    ~LanRes() {
+        if (device >= 0) (void)hipSetDevice(device);
+        if (h_rec) (void)hipHostFree(h_rec);
+        if (h_y) (void)hipHostFree(h_y);
+        if (have_events)
+            for (int i = 0; i < LAN_SLOTS; ++i) {
+                (void)hipEventDestroy(ev_done[i]);
+                (void)hipEventDestroy(ev_mv0[i]);
+                (void)hipEventDestroy(ev_mv1[i]);
+            }
+    }
+};
+std::mutex g_lan_mu;
+std::map<hipStream_t, std::unique_ptr<LanRes>> g_lan_res;
+
+int lan_res_get(hipStream_t st, LanRes** out) {
+    std::lock_guard<std::mutex> lk(g_lan_mu);
+    auto& slot = g_lan_res[st];
+    if (!slot) {
+        auto r = std::make_unique<LanRes>();
+        HIP_TRY(hipGetDevice(&r->device));
+        HIP_TRY(hipHostMalloc((void**)&r->h_rec, sizeof(LanRecord) * LAN_SLOTS, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(r->h_rec, 0, sizeof(LanRecord) * LAN_SLOTS);      // (before any device work can see the block)
+        HIP_TRY(hipHostGetDevicePointer((void**)&r->d_rec, r->h_rec, 0));
+        HIP_TRY(hipHostMalloc((void**)&r->h_y, sizeof(double2) * LAN_SLOTS, hipHostMallocDefault));
+        for (int i = 0; i < LAN_SLOTS; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&r->ev_done[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreate(&r->ev_mv0[i]));
+            HIP_TRY(hipEventCreate(&r->ev_mv1[i]));
+        }
+        r->have_events = true;
+        slot = std::move(r);
+    }
+    *out = slot.get();
+    return 0;
+}
+}  // namespace
+
+void htn_krylov_release_stream(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_lan_mu);
+    g_lan_res.erase(st);
 }
 
 extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, int32_t x_slot, int32_t y_slot,
@@ -414,40 +495,22 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
                              double* matvec_ms_host, void* stream_v) {
     hipStream_t st = (hipStream_t)stream_v;
     const int kd = krylovdim;
-    if (kd < 2 || kd > 63) return fail_msg("htn_lanczos_z: krylovdim must be in 2..63");
+    // (k_axpy_dots keeps one basis value per Krylov vector in registers: at most DOT_CHUNK = 32 vectors per step)
+    if (kd < 2 || kd + 1 > DOT_CHUNK) return fail_msg("htn_lanczos_z: krylovdim must be in 2..31");
     double2* V = (double2*)Vv;
     double2* partial = (double2*)scratch;
     double2* partial2 = partial + (int64_t)(kd + 1) * DOT_BLOCKS;
-    double2* c1 = partial2 + (int64_t)(kd + 1) * DOT_BLOCKS;
+    double2* c1 = partial2 + (int64_t)(kd + 1) * DOT_BLOCKS;      // device scalars <v_j, w>: first / second pass
     double2* c2 = c1 + (kd + 1);
     double2* ycoef = c2 + (kd + 1);
     double* norm_partial = (double*)(ycoef + (kd + 1));
-    double* nrm2 = norm_partial + DOT_BLOCKS;
 
-    // host-pinned, device-mapped: the kernels write alpha / beta^2 straight into host memory (no copy
-    // kernel per iteration); valid on the host once the iteration's event has completed
-    static thread_local double2* h_c = nullptr;
-    static thread_local double2* d_c = nullptr;
-    static thread_local hipEvent_t ev_done[64], ev_mv0[64], ev_mv1[64];
-    if (!h_c) {
-        HIP_TRY(hipHostMalloc((void**)&h_c, sizeof(double2) * (4 * 64), hipHostMallocMapped));
-        HIP_TRY(hipHostGetDevicePointer((void**)&d_c, h_c, 0));
-        for (int i = 0; i < 64; ++i) {
-            HIP_TRY(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreate(&ev_mv0[i]));
-            HIP_TRY(hipEventCreate(&ev_mv1[i]));
-        }
-    }
-    double2* h_c1 = h_c;                    // [64] <v_j, w> of the first Gram-Schmidt pass
-    double2* h_c2 = h_c + 64;               // [64] second pass
-    double* h_n = (double*)(h_c + 128);     // [64] |w|^2 after orthogonalisation, one slot per iteration
-    double2* h_y = h_c + 192;               // Ritz coefficients staging
-    c1 = d_c;                               // device views of the pinned block
-    c2 = d_c + 64;
-    nrm2 = (double*)(d_c + 128);
+    LanRes* R = nullptr;
+    if (lan_res_get(st, &R)) return 1;
+    const bool event_waits = htn_debug_event_waits();
 
-    bool timed_step[64] = {false};
-    static thread_local unsigned step_serial = 0;
+    bool timed_step[LAN_SLOTS] = {false};
+    unsigned long long step_serial[LAN_SLOTS] = {0};
     auto matvec = [&](double2* x, double2* y) -> int {
         if (zero_y) HIP_TRY(hipMemsetAsync(y, 0, sizeof(double2) * n, st));
         for (int s = 0; s < n_stages; ++s) {
@@ -460,38 +523,57 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         if (exchange && exchange(y, n, user)) return fail_msg("htn_lanczos_z: the exchange hook reported a failure");
         return 0;
     };
-    // one Lanczos step, fully enqueued: w = H v_j; two Gram-Schmidt passes against V[0..j]; v_{j+1} = w/|w|
+    // one Lanczos step, fully enqueued: w = H v_j; two Gram-Schmidt passes against V[0..j]; v_{j+1} = w/|w|; the last
+    // kernel publishes the step's record under a fresh serial
     auto enqueue_step = [&](int j) -> int {
         double2* vj = V + (int64_t)j * n;
         double2* w = V + (int64_t)(j + 1) * n;
         // HIP events around a SAMPLE of the matvec launches (every 8th): an event is a marker packet that costs ~5 us
         // of pipeline bubble on this part, three of them per step were 15 us of a ~105 us Lanczos step
-        const bool timed = matvec_ms_host && (step_serial % 8) == 0;
+        const bool timed = matvec_ms_host && (R->sample % 8) == 0;
         timed_step[j] = timed;
-        ++step_serial;
-        h_n[j] = -1.0;                               // sentinel: the step's last kernel overwrites it with |w|^2 >= 0
-        if (timed) HIP_TRY(hipEventRecord(ev_mv0[j], st));
+        ++R->sample;
+        step_serial[j] = ++R->serial;
+        if (timed) HIP_TRY(hipEventRecord(R->ev_mv0[j], st));
         if (matvec(vj, w)) return 1;
-        if (timed) HIP_TRY(hipEventRecord(ev_mv1[j], st));
+        if (timed) HIP_TRY(hipEventRecord(R->ev_mv1[j], st));
         // two-pass classical Gram-Schmidt in three passes over the basis: dots | update + dots (fused) | update + norm
         launch_dots_partial(V, n, j + 1, w, n, partial, st);
         launch_axpy_dots(w, V, n, j + 1, partial, c1 + j, j, -1.0, n, partial2, st);
         hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial2, c2 + j, j,
                            -1.0, n, norm_partial);
-        hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, w, w, norm_partial, n, nrm2 + j);
+        hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, w, w, norm_partial, n, R->d_rec + j,
+                           (const double2*)(c1 + j), (const double2*)(c2 + j), step_serial[j]);
+        if (event_waits) HIP_TRY(hipEventRecord(R->ev_done[j], st));
         return 0;
     };
-    // wait for step j's scalars: spin on the pinned slot the step's last kernel writes (alpha was written by kernels
-    // that completed before it started: same stream).  A stream that has gone idle without the slot changing means
-    // the step never ran (a fault): report instead of spinning forever.
-    auto wait_step = [&](int j) -> int {
-        volatile double* slot = h_n + j;
+    // read slot j if it holds the record of THIS step (see LanRecord): true = accepted
+    auto read_record = [&](int j, double* a1, double* a2, double* nn) -> bool {
+        const volatile unsigned long long* p = R->h_rec[j].w;
+        const unsigned long long w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+        if (w3 != lan_check(w0, w1, w2, step_serial[j])) return false;
+        memcpy(a1, &w0, 8);
+        memcpy(a2, &w1, 8);
+        memcpy(nn, &w2, 8);
+        return true;
+    };
+    // wait for step j's record.  Product path: poll the slot (the host wakes within the PCIe latency of the store; a
+    // sleeping wait costs tens of us per step).  A stream that has drained without the record arriving means the step never
+    // ran to its end (a fault): report instead of spinning forever.  HTN_DEBUG_EVENT_WAITS: wait for the step's event, after
+    // which the record MUST validate.
+    auto wait_step = [&](int j, double* a1, double* a2, double* nn) -> int {
+        if (event_waits) {
+            HIP_TRY(hipEventSynchronize(R->ev_done[j]));
+            if (!read_record(j, a1, a2, nn)) return fail_msg("htn_lanczos_z: the step's event completed but its record does not validate");
+            return 0;
+        }
         for (unsigned spins = 1;; ++spins) {
-            if (*slot >= 0.0) return 0;
+            if (read_record(j, a1, a2, nn)) return 0;
             __builtin_ia32_pause();
             if ((spins & 0xffff) == 0) {
                 const hipError_t q = hipStreamQuery(st);
-                if (q == hipSuccess) return *slot >= 0.0 ? 0 : fail_msg("htn_lanczos_z: the stream drained without producing the step's norm");
+                if (q == hipSuccess)
+                    return read_record(j, a1, a2, nn) ? 0 : fail_msg("htn_lanczos_z: the stream drained without producing the step's record");
                 if (q != hipErrorNotReady) return fail("hipStreamQuery", q);
             }
         }
@@ -500,16 +582,16 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
     // normalise the start vector
     hipLaunchKernelGGL(k_norm_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, norm_partial);
     hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, V, V, norm_partial, n,
-                       (double*)nullptr);
+                       (LanRecord*)nullptr, (const double2*)nullptr, (const double2*)nullptr, 0ull);
     double mv_ms = 0.0;
     int nmv = 0, n_timed = 0;
     double theta = 0.0, res = 0.0, beta = 0.0, amax = 0.0;
     std::vector<double> y;
     for (int restart = 0; restart <= max_restart; ++restart) {
         std::vector<double> alphas, betas;
-        // Software pipeline of depth 1: step j+1 is enqueued BEFORE the host waits for step j's scalars, so the
+        // Software pipeline of depth 1: step j+1 is enqueued BEFORE the host waits for step j's record, so the
         // GPU never idles during the host's convergence test.  If step j converges, step j+1 was speculative:
-        // it only wrote Krylov row j+2 and scalar slots j+1, which nothing reads afterwards.
+        // it only wrote Krylov row j+2, device scalars j+1 and record slot j+1, which nothing reads afterwards.
         if (enqueue_step(0)) return 1;
         ++nmv;
         for (int j = 0; j < kd; ++j) {
@@ -517,16 +599,18 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
                 if (enqueue_step(j + 1)) return 1;
                 ++nmv;
             }
-            if (wait_step(j)) return 1;
+            double a1 = 0.0, a2 = 0.0, nn = 0.0;
+            if (wait_step(j, &a1, &a2, &nn)) return 1;
             if (timed_step[j]) {
                 float ms = 0.f;
-                HIP_TRY(htn_event_spin(ev_mv1[j]));
-                HIP_TRY(hipEventElapsedTime(&ms, ev_mv0[j], ev_mv1[j]));
+                HIP_TRY(htn_event_spin(R->ev_mv1[j]));
+                HIP_TRY(hipEventElapsedTime(&ms, R->ev_mv0[j], R->ev_mv1[j]));
                 mv_ms += ms;
                 ++n_timed;
             }
-            const double alpha = h_c1[j].x + h_c2[j].x;
-            beta = sqrt(h_n[j] > 0.0 ? h_n[j] : 0.0);
+            const double alpha = a1 + a2;
+            if (!(alpha == alpha) || !(nn == nn)) return fail_msg("htn_lanczos_z: NaN in the tridiagonal coefficients (operator or start vector not finite)");
+            beta = sqrt(nn > 0.0 ? nn : 0.0);
             alphas.push_back(alpha);
             tridiag_lowest(alphas, betas, &theta, y);
             res = fabs(beta * y.back());
@@ -538,14 +622,14 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         HIP_TRY(htn_stream_spin(st));       // drain the speculative step before rows are reused
         // x = sum_i y_i V_i  -> scratch row kd+1, normalised into row 0
         const int k = (int)y.size();
-        for (int i = 0; i < k; ++i) h_y[i] = make_double2(y[i], 0.0);
-        HIP_TRY(hipMemcpyAsync(ycoef, h_y, sizeof(double2) * k, hipMemcpyHostToDevice, st));
+        for (int i = 0; i < k; ++i) R->h_y[i] = make_double2(y[i], 0.0);
+        HIP_TRY(hipMemcpyAsync(ycoef, R->h_y, sizeof(double2) * k, hipMemcpyHostToDevice, st));
         double2* xrow = V + (int64_t)(kd + 1) * n;
         HIP_TRY(hipMemsetAsync(xrow, 0, sizeof(double2) * n, st));
         hipLaunchKernelGGL(k_axpys, dim3(grid_for(n)), dim3(256), 0, st, xrow, V, n, k, ycoef, 1.0, n);
         hipLaunchKernelGGL(k_norm_partial, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, xrow, n, norm_partial);
         hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, V, xrow, norm_partial, n,
-                           (double*)nullptr);
+                           (LanRecord*)nullptr, (const double2*)nullptr, (const double2*)nullptr, 0ull);
         HIP_TRY(htn_stream_spin(st));      // h_y is reused by the next restart / call
         if (res < tol || beta < 1e-14 * std::max(amax, 1e-300)) break;
     }

@@ -1,6 +1,8 @@
 // batched Jacobi SVD + strided copy kernels (libhubbardtn_hip.so)
-#include <mutex>
 #include <algorithm>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "htn_common.h"
@@ -1196,27 +1198,73 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_finish(double2* __restri
     if (tid == 0) info[b] = done[blockIdx.x] ? sweeps[blockIdx.x] : -sweeps[blockIdx.x];
 }
 
-// thread-local device scratch of the multi-launch path (grown on demand)
+// per-stream scratch of the multi-launch path (grown on demand; htn_common.h: owned by the stream's registry entry and
+// released by the backend that owns the stream)
 struct JacScratch {
+    int device = -1;
     void* dev = nullptr;
     size_t bytes = 0;
-    void* pinned = nullptr;
+    void* pinned = nullptr;             // host -> device staging (work lists, ids)
     size_t pinned_bytes = 0;
+    int* flags = nullptr;               // device -> host: [active count per sweep | rank per large block]; coherent, its own block
+    int* flags_dev = nullptr;           // device view of it
+    size_t flags_elems = 0;
     hipStream_t aux = nullptr;          // forked stream: small blocks run beside the large-block pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sweep[2] = {nullptr, nullptr};
+    ~JacScratch() {
+        if (device >= 0) (void)hipSetDevice(device);
+        if (aux) {
+            (void)hipStreamSynchronize(aux);
+            (void)hipStreamDestroy(aux);
+            (void)hipEventDestroy(ev_fork);
+            (void)hipEventDestroy(ev_join);
+            (void)hipEventDestroy(ev_sweep[0]);
+            (void)hipEventDestroy(ev_sweep[1]);
+        }
+        if (dev) (void)hipFree(dev);
+        if (pinned) (void)hipHostFree(pinned);
+        if (flags) (void)hipHostFree(flags);
+    }
 };
-static thread_local JacScratch g_js;
+static std::mutex g_js_mu;
+static std::map<hipStream_t, std::unique_ptr<JacScratch>> g_js_res;
 
-static int js_reserve(size_t dev_bytes, size_t pin_bytes) {
+void htn_svd_release_stream(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_js_mu);
+    g_js_res.erase(st);
+}
+
+static int js_get(hipStream_t st, JacScratch** out) {
+    std::lock_guard<std::mutex> lk(g_js_mu);
+    auto& slot = g_js_res[st];
+    if (!slot) {
+        slot = std::make_unique<JacScratch>();
+        HIP_TRY(hipGetDevice(&slot->device));
+    }
+    *out = slot.get();
+    return 0;
+}
+
+static int js_reserve(JacScratch& g_js, size_t dev_bytes, size_t pin_bytes, size_t flag_elems) {
     if (dev_bytes > g_js.bytes) {
         if (g_js.dev) HIP_TRY(hipFree(g_js.dev));
+        g_js.dev = nullptr, g_js.bytes = 0;
         HIP_TRY(hipMalloc(&g_js.dev, dev_bytes * 2));
+        if (htn_debug_poison()) HIP_TRY(hipMemset(g_js.dev, 0xFF, dev_bytes * 2));
         g_js.bytes = dev_bytes * 2;
     }
     if (pin_bytes > g_js.pinned_bytes) {
         if (g_js.pinned) HIP_TRY(hipHostFree(g_js.pinned));
-        HIP_TRY(hipHostMalloc(&g_js.pinned, pin_bytes * 2));
+        g_js.pinned = nullptr, g_js.pinned_bytes = 0;
+        HIP_TRY(hipHostMalloc(&g_js.pinned, pin_bytes * 2, hipHostMallocDefault));
         g_js.pinned_bytes = pin_bytes * 2;
+    }
+    if (flag_elems > g_js.flags_elems) {
+        if (g_js.flags) HIP_TRY(hipHostFree(g_js.flags));
+        g_js.flags = nullptr, g_js.flags_elems = 0;
+        HIP_TRY(hipHostMalloc((void**)&g_js.flags, sizeof(int) * flag_elems * 2, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer((void**)&g_js.flags_dev, g_js.flags, 0));
+        g_js.flags_elems = flag_elems * 2;
     }
     if (!g_js.aux) {
         HIP_TRY(hipStreamCreateWithFlags(&g_js.aux, hipStreamNonBlocking));
@@ -1326,7 +1374,11 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     const size_t off_ratio = (off_zero + sizeof(double) * nl + 7) / 8 * 8, off_done = off_ratio + 8 * nl;
     const size_t off_sw = off_done + sizeof(int) * nl, off_items = (off_sw + sizeof(int) * nl + 31) / 32 * 32;
     const size_t dev_bytes = off_items + sizeof(JacPairItem) * n_items_max;
-    if (js_reserve(dev_bytes, sizeof(JacPairItem) * n_items_max + 24 * nl + 4 * n_blocks + 4 * (size_t)(max_sweeps + 1) + 128))
+    JacScratch* jsp = nullptr;
+    if (js_get(st, &jsp)) return 1;
+    JacScratch& g_js = *jsp;
+    if (js_reserve(g_js, dev_bytes, sizeof(JacPairItem) * n_items_max + 4 * (size_t)(nl + n_blocks) + 128,
+                   (size_t)(max_sweeps + 1) + (size_t)nl + 16))
         return 1;
     char* d = (char*)g_js.dev;
     int* d_ids = (int*)(d + off_ids);
@@ -1337,14 +1389,16 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     int* d_done = (int*)(d + off_done);
     int* d_sw = (int*)(d + off_sw);
     JacPairItem* d_items = (JacPairItem*)(d + off_items);
-    // pinned staging: [items | ids | slot of every block | active count per sweep | rank per large block]
-    // (the last two are written by the device)
+    // pinned staging (host -> device): [items | ids | slot of every block]; device -> host flags (their own coherent
+    // block, read by the host only behind a completed event): [active count per sweep | rank per large block]
     char* h = (char*)g_js.pinned;
     JacPairItem* h_items = (JacPairItem*)h;
     int* h_ids = (int*)(h + sizeof(JacPairItem) * n_items_max);
     int* h_slot = h_ids + nl;                        // [ids | slot] contiguous like the device copy: ONE upload
-    volatile int* h_active = (volatile int*)(h_slot + n_blocks);
+    volatile int* h_active = (volatile int*)g_js.flags;
     volatile int* h_rank = h_active + (max_sweeps + 1);
+    int* d_active = g_js.flags_dev;
+    int* d_rank = d_active + (max_sweeps + 1);
     for (int b = 0; b < n_blocks; ++b) h_slot[b] = -1;
     for (int li = 0; li < nl; ++li) h_slot[large[li]] = li;
     for (int li = 0; li < nl; ++li) h_ids[li] = large[li];
@@ -1382,7 +1436,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         for (int li = 0; li < nl; ++li) max_m0 = std::max(max_m0, (int)desc_host[large[li]].pad);
         const size_t qr_lds = (size_t)16 * (((max_m0 + 15) & ~15) + 1) * sizeof(double2);
         hipLaunchKernelGGL(k_qr_large, dim3(nl), dim3(JAC_THREADS), qr_lds, st, (double2*)G, (double2*)Vj, desc, d_ids,
-                           d_perm, d_zero, cut2, (int*)h_rank);
+                           d_perm, d_zero, cut2, d_rank);
     }
     if (cut2 > 0.0) {        // the tournament is sized by the ranks the QR found: wait for them (one sync per call)
         HIP_TRY(hipEventRecord(g_js.ev_sweep[0], st));
@@ -1400,7 +1454,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
                 hipLaunchKernelGGL(k_jacobi_pairs_gram, dim3((unsigned)rounds[r].size()), dim3(256), gram_lds_bytes, st,
                                    (double2*)Vj, desc, d_ids, d_items + r_off[r], d_zero, d_ratio, d_done, tol, 1);
         hipLaunchKernelGGL(k_jacobi_check, dim3(1), dim3(64), 0, st, d_ratio, d_done, d_sw, nl, thr,
-                           (int*)h_active + sweep);
+                           d_active + sweep);
         return hipEventRecord(g_js.ev_sweep[sweep & 1], st);
     };
     // Speculation is bounded by the caller's expectation (htn_svd_opts.sweeps_hint, normally what the previous update of

@@ -185,6 +185,13 @@ struct CpuBackend : Backend {
     void* alloc(size_t bytes) override {
         void* p = nullptr;
         if (posix_memalign(&p, 64, std::max<size_t>(bytes, 64))) return nullptr;
+        // HTN_DEBUG_POISON (test switch, same meaning as in the HIP backend): blocks start as 0xFF bytes (NaN), so a planner
+        // that leaves part of a buffer unwritten shows up as NaN instead of depending on what malloc returned
+        static const bool poison = [] {
+            const char* v = getenv("HTN_DEBUG_POISON");
+            return v && v[0] && v[0] != '0';
+        }();
+        if (poison) memset(p, 0xFF, std::max<size_t>(bytes, 64));
         return p;
     }
     void release(void* p) override { free(p); }

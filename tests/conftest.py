@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# A red run must say as much as possible as early as possible (pytest -x stops at the first failure): the cheap,
+# diagnostic tests run first -- kernels vs numpy / LAPACK, then the debug-switch runs, the engine vs oracle / ED, the API,
+# IDMRG2 -- and the long full-size trajectories last.  Files not named here keep their place in front.
+_ORDER = ["test_kernels_gpu", "test_debug_gpu", "test_engine_gpu", "test_api_gpu", "test_idmrg_gpu", "test_fullsize_gpu"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(name) if name in _ORDER else -1
+    items.sort(key=rank)          # stable: the order inside a file is kept
+
+
 @pytest.fixture(scope="session")
 def hip_ops():
     from hubbardtn_amd.device import HipOps
