@@ -1198,6 +1198,411 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_finish(double2* __restri
     if (tid == 0) info[b] = done[blockIdx.x] ? sweeps[blockIdx.x] : -sweeps[blockIdx.x];
 }
 
+// =====================================================================================================================
+// Ring block Jacobi: the large blocks' sweeps in ONE launch
+// =====================================================================================================================
+// The multi-launch path above pays, per tournament round, a kernel boundary plus a visit that re-derives everything from
+// global memory (columns -> LDS, Gram, P U back): 15 us per round, ~210 dependent rounds per centre bond at chi = 1024, with
+// a tenth of the chip busy.  Here a block of n columns is given P workgroups (one per CU, 1024 threads) that stay resident
+// for ALL sweeps.  The columns are cut into 2 P panels of w columns; every workgroup keeps two panels in LDS (w * mp <= 4608
+// elements each) and plays the classic round-robin ("caterpillar") tournament on panels: in each of the 2 P - 1 rounds of a
+// sweep it rotates its w x w cross pairs directly on the LDS-resident columns (plain one-sided rotations, one group of GS
+// lanes per pair, the panel-T column of a group kept in registers for the whole round), then the panels move one position:
+// top panels to the next workgroup, bottom panels to the previous one (workgroup 0 keeps its top, the last one turns its
+// top into its bottom).  Once per sweep the pairs INSIDE the resident panels are rotated.  A sweep costs
+// (2 P - 1) x (w steps of ~0.5 us + one panel exchange) instead of ~(n / 8) x 15 us.
+//
+// Hand-off between workgroups inside the launch (cdna_hip_programming.md section 6, Guideline 16, form R1 / first table row of
+// MI355X_MICROARCH.md "visibility"): the payload goes out as 16-byte WRITE-THROUGH (sc1) stores into the receiver's mailbox,
+// every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane stores the round's epoch into the receiver's
+// flag with an agent-scope atomic store; the receiver polls that one word with relaxed agent-scope loads from ONE lane,
+// workgroup barrier, then EVERY load of the payload is an sc1 load.  No placement assumption: correctness does not depend on
+// which CU or XCD a workgroup landed on.  Mailbox slots alternate by epoch parity; neighbours exchange in both directions in
+// every round, so a sender can be at most one round ahead of its receiver and never overwrites a slot that is still unread.
+// All workgroups of a launch are co-resident (the host caps the grid at the CU count; LDS use forces one per CU); every poll
+// is bounded by wall-clock time and a shared failure word, so a launch always drains.
+#define RING_THREADS 1024
+#define RING_PANEL_ELEMS 4608         // complex128 elements of one resident panel (2 panels = 144 KiB of LDS)
+#define RING_MAX_P 64
+struct RingItem {
+    int32_t li;        // large-block index (large_ids[li] = block in desc)
+    int32_t k, P;      // CU slot of this workgroup, CU slots of the block
+    int32_t w;         // panel width: panel q = columns [q w, min((q + 1) w, n))
+    int32_t n;         // columns taking part (the rank the QR found, <= desc.n)
+    int32_t g0;        // grid index of the block's slot 0 (flag addressing)
+    int64_t mbox;      // element offset of the block's mailboxes: slot k owns 4 slots [role][parity] of w * mp elements
+};                     // 32 bytes
+typedef unsigned int ring_u4 __attribute__((ext_vector_type(4)));
+__host__ __device__ __forceinline__ int ring_gs(int m) { return m <= 64 ? 16 : (m <= 128 ? 32 : 64); }
+
+// one lane polls one word (relaxed, agent scope); false: timed out or another workgroup reported failure
+__device__ __forceinline__ bool ring_wait_ge(unsigned* flag, unsigned want, unsigned* fail) {
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 1;; ++spins) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 255u) == 0u) {
+            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (wall_clock64() - t0 > 300000000ll) {             // 3 s of the 100 MHz constant clock
+                __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+// LDS panel (cnt contiguous elements) -> mailbox slot, 16-byte sc1 stores (the caller drains and raises the flag)
+__device__ __forceinline__ void ring_send(const double2* __restrict__ src, double2* slot, int cnt, int tid) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slot, 0, cnt * 16, 0x00020000);
+    for (int idx = tid; idx < cnt; idx += RING_THREADS) {
+        const double2 v = src[idx];
+        ring_u4 u;
+        __builtin_memcpy(&u, &v, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(u, rs, idx * 16, 0, 16);       // aux 16 = sc1
+    }
+}
+// mailbox slot -> LDS panel, every load sc1; all loads of a thread in flight together (cnt <= 5 * 1024)
+__device__ __forceinline__ void ring_recv(double2* dst, const double2* slot, int cnt, int tid) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slot, 0, cnt * 16, 0x00020000);
+    // (unconditional loads: the descriptor's range check returns zeros beyond cnt, and a conditionally filled register
+    // array makes the compiler carry -- and spill -- the whole array as one tuple)
+    const ring_u4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 0 * RING_THREADS) * 16, 0, 16);
+    const ring_u4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 1 * RING_THREADS) * 16, 0, 16);
+    const ring_u4 u2 = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 2 * RING_THREADS) * 16, 0, 16);
+    const ring_u4 u3 = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 3 * RING_THREADS) * 16, 0, 16);
+    const ring_u4 u4 = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 4 * RING_THREADS) * 16, 0, 16);
+    auto put = [&](int idx, ring_u4 u) {
+        if (idx < cnt) {
+            double2 v;
+            __builtin_memcpy(&v, &u, 16);
+            dst[idx] = v;
+        }
+    };
+    put(tid + 0 * RING_THREADS, u0);
+    put(tid + 1 * RING_THREADS, u1);
+    put(tid + 2 * RING_THREADS, u2);
+    put(tid + 3 * RING_THREADS, u3);
+    put(tid + 4 * RING_THREADS, u4);
+}
+
+// rotation of a column pair held in registers (the arithmetic of jacobi_pair_pad); returns the squared cosine seen
+template <int GS, int E>
+__device__ __forceinline__ double ring_rotate(double2 (&a)[E], double2 (&b)[E], double tol2, double zero2) {
+    double aa = 0.0, bb = 0.0, gr = 0.0, gi = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        aa = fma(a[e].x, a[e].x, fma(a[e].y, a[e].y, aa));
+        bb = fma(b[e].x, b[e].x, fma(b[e].y, b[e].y, bb));
+        gr = fma(a[e].x, b[e].x, fma(a[e].y, b[e].y, gr));      // conj(a) * b
+        gi = fma(a[e].x, b[e].y, fma(-a[e].y, b[e].x, gi));
+    }
+    aa = group_sum<GS>(aa);
+    bb = group_sum<GS>(bb);
+    gr = group_sum<GS>(gr);
+    gi = group_sum<GS>(gi);
+    if (aa <= zero2 || bb <= zero2) return 0.0;
+    const double g2 = gr * gr + gi * gi;
+    const double ab = aa * bb;
+    const double ratio2 = g2 * fast_rcp(ab);
+    if (g2 == 0.0 || g2 <= tol2 * ab) return ratio2;
+    const double ig = fast_rsq(g2);
+    const double g = g2 * ig;
+    const double h = bb - aa;
+    const double w2 = fma(h, h, 4.0 * g2);
+    const double w = w2 * fast_rsq(w2);
+    double t = 2.0 * g * fast_rcp(fabs(h) + w);
+    t = h >= 0.0 ? t : -t;
+    const double c = fast_rsq(fma(t, t, 1.0));
+    const double s = c * t;
+    const double sr = s * gr * ig, si = -s * gi * ig;           // sig = s exp(-i phi), tau = c exp(-i phi)
+    const double tr = c * gr * ig, ti = -c * gi * ig;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        double2 na, nb;
+        na.x = fma(c, a[e].x, fma(-sr, b[e].x, si * b[e].y));
+        na.y = fma(c, a[e].y, fma(-sr, b[e].y, -si * b[e].x));
+        nb.x = fma(s, a[e].x, fma(tr, b[e].x, -ti * b[e].y));
+        nb.y = fma(s, a[e].y, fma(tr, b[e].y, ti * b[e].x));
+        a[e] = na;
+        b[e] = nb;
+    }
+    return ratio2;
+}
+
+// all nt x nb cross pairs of the two resident panels: group g owns T column g in registers, B columns pass through LDS
+template <int GS, int E>
+__device__ __forceinline__ double ring_cross(double2* T, double2* B, int nt, int nb, int tid, double tol2, double zero2) {
+    constexpr int mp = GS * E;
+    const int grp = tid / GS, sub = tid % GS;
+    const int wm = nt > nb ? nt : nb;
+    double ratio = 0.0;
+    if (nt == 0 || nb == 0) return ratio;                      // (uniform over the workgroup)
+    const bool own = grp < nt;
+    double2 a[E];
+    if (own) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) a[e] = T[grp * mp + sub + GS * e];
+    }
+    for (int s = 0; s < wm; ++s) {
+        int j = grp + s;
+        j = j >= wm ? j - wm : j;
+        if (own && j < nb) {
+            double2 b[E];
+            double2* bc = B + j * mp + sub;
+#pragma unroll
+            for (int e = 0; e < E; ++e) b[e] = bc[GS * e];
+            const double rr = ring_rotate<GS, E>(a, b, tol2, zero2);
+            ratio = rr > ratio ? rr : ratio;
+#pragma unroll
+            for (int e = 0; e < E; ++e) bc[GS * e] = b[e];
+        }
+        __syncthreads();
+    }
+    if (own) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) T[grp * mp + sub + GS * e] = a[e];
+    }
+    __syncthreads();
+    return ratio;
+}
+
+// the pairs inside each resident panel (circle tournament per panel, both panels side by side)
+template <int GS, int E>
+__device__ __forceinline__ double ring_intra(double2* T, int nt, double2* B, int nb, int tid, double tol2, double zero2) {
+    constexpr int mp = GS * E;
+    const int grp = tid / GS, sub = tid % GS;
+    const int npT = nt + (nt & 1), npB = nb + (nb & 1), hT = npT >> 1, hB = npB >> 1;
+    const int steps = (npT > npB ? npT : npB) - 1;
+    double ratio = 0.0;
+    for (int r = 0; r < steps; ++r) {
+        double2* base = nullptr;
+        int np = 0, pn = 0, p = 0;
+        if (grp < hT) base = T, np = npT, pn = nt, p = grp;
+        else if (grp < hT + hB) base = B, np = npB, pn = nb, p = grp - hT;
+        if (base && r < np - 1) {
+            const int md = np - 1;
+            int i, j;
+            if (p == 0) i = np - 1, j = r;
+            else {
+                i = r + p;
+                i = i >= md ? i - md : i;
+                j = r + md - p;
+                j = j >= md ? j - md : j;
+            }
+            if (i < pn && j < pn) {
+                const int lo = i < j ? i : j, hi = i < j ? j : i;
+                const double rr = jacobi_pair_pad<GS, E>(base + lo * mp, base + hi * mp, sub, tol2, zero2);
+                ratio = rr > ratio ? rr : ratio;
+            }
+        }
+        __syncthreads();
+    }
+    return ratio;
+}
+
+struct RingArgs {
+    double2* Vj;
+    double2* G;
+    double* S;
+    const htn_svd_block* desc;
+    const int* large_ids;
+    const RingItem* items;
+    const int* perm;
+    const double* zero2;
+    double2* mbox;
+    unsigned* sync;              // [flags: 2 per workgroup | arrive: nl * max_sweeps | fail | pad | conv (u64): nl * max_sweeps]
+    int arrive_off, fail_off, conv_off;      // in 32-bit words (conv_off even)
+    int max_sweeps;
+    double tol;
+    int* info;
+    int* sweeps_out;             // host-mapped, [nl]: outer sweeps of each block (0 = failed)
+};
+
+template <int GS, int E>
+__device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, const htn_svd_block D, double2* lds, int* s_top, int* s_bot,
+                         unsigned long long* s_rbits, int* s_ok) {
+    constexpr int mp = GS * E;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = it.P, k = it.k, w = it.w, n = it.n, m = D.m;
+    double2* __restrict__ X = A.Vj + D.v_off;
+    const int slot_elems = w * mp;
+    double2* bufT = lds;
+    double2* bufB = lds + slot_elems;
+    unsigned* flags = A.sync;
+    unsigned* fail = A.sync + A.fail_off;
+    const double zero2 = A.zero2[it.li];
+    const double tol2 = A.tol * A.tol, thr = fmax(tol2, 0.1 * A.tol);
+    auto ncols = [&](int q) {
+        const int c = n - q * w;
+        return c < 0 ? 0 : (c > w ? w : c);
+    };
+    if (tid < P) {
+        s_top[tid] = 2 * tid;
+        s_bot[tid] = 2 * tid + 1;
+    }
+    if (tid == 0) *s_ok = 1;
+    __syncthreads();
+    {   // resident panels <- X (written by the QR kernel before this launch: plain loads), re-padded from X's leading
+        // dimension (the rule of the one-workgroup kernel) to mp rows; rows >= m are zero in both
+        const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
+        const int ldx = gsx * ((m + gsx - 1) / gsx);
+        for (int side = 0; side < 2; ++side) {
+            const int q = side ? s_bot[k] : s_top[k];
+            double2* buf = side ? bufB : bufT;
+            const int cnt = ncols(q) * mp;
+            for (int idx = tid; idx < cnt; idx += RING_THREADS) {
+                const int c = idx / mp, i = idx - c * mp;
+                buf[idx] = i < m ? X[(int64_t)(q * w + c) * ldx + i] : make_double2(0.0, 0.0);
+            }
+        }
+    }
+    __syncthreads();
+    int sweeps = 0;
+    bool done = n < 2, ok = true;
+    const int rounds = 2 * P - 1;
+    while (!done && ok && sweeps < A.max_sweeps) {
+        double ratio = 0.0;
+        for (int r = 0; r < rounds && ok; ++r) {
+            const unsigned epoch = (unsigned)(sweeps * rounds + r + 1);
+            const int par = (int)(epoch & 1u);
+            const int nt = ncols(s_top[k]), nb = ncols(s_bot[k]);
+            const double rr = ring_cross<GS, E>(bufT, bufB, nt, nb, tid, tol2, zero2);
+            ratio = rr > ratio ? rr : ratio;
+            if (P < 2) continue;
+            // ---- panels move one position: send, drain, raise the flags ----
+            double2* box = A.mbox + it.mbox;                    // slot of workgroup kd, role, parity: ((kd * 2 + role) * 2 + par)
+            if (k == 0) ring_send(bufB, box + (int64_t)((1 * 2 + 0) * 2 + par) * slot_elems, nb * mp, tid);            // bottom -> top of 1
+            else {
+                if (k < P - 1) ring_send(bufT, box + (int64_t)(((k + 1) * 2 + 0) * 2 + par) * slot_elems, nt * mp, tid);   // top -> top of k + 1
+                ring_send(bufB, box + (int64_t)(((k - 1) * 2 + 1) * 2 + par) * slot_elems, nb * mp, tid);                  // bottom -> bottom of k - 1
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                if (k == 0) __hip_atomic_store(flags + (it.g0 + 1) * 2 + 0, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else {
+                    if (k < P - 1) __hip_atomic_store(flags + (it.g0 + k + 1) * 2 + 0, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(flags + (it.g0 + k - 1) * 2 + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // the panel ids follow the same permutation in every workgroup of the block
+                const int t_last = s_top[P - 1], b0 = s_bot[0];
+                for (int q = P - 1; q >= 2; --q) s_top[q] = s_top[q - 1];
+                s_top[1] = b0;
+                for (int q = 0; q + 1 < P; ++q) s_bot[q] = s_bot[q + 1];
+                s_bot[P - 1] = t_last;
+                // ---- wait for what comes in ----
+                bool good = true;
+                if (k > 0) good = ring_wait_ge(flags + (it.g0 + k) * 2 + 0, epoch, fail);
+                if (good && k < P - 1) good = ring_wait_ge(flags + (it.g0 + k) * 2 + 1, epoch, fail);
+                if (!good) *s_ok = 0;
+            }
+            if (k == P - 1) {           // the last workgroup's top panel becomes its bottom panel: swap the roles of the buffers
+                double2* t = bufT;
+                bufT = bufB;
+                bufB = t;
+            }
+            __syncthreads();
+            ok = *s_ok != 0;
+            if (ok) {
+                const double2* mine = box + (int64_t)(k * 4) * slot_elems;
+                if (k > 0) ring_recv(bufT, mine + (int64_t)(0 * 2 + par) * slot_elems, ncols(s_top[k]) * mp, tid);
+                if (k < P - 1) ring_recv(bufB, mine + (int64_t)(1 * 2 + par) * slot_elems, ncols(s_bot[k]) * mp, tid);
+            }
+            __syncthreads();
+        }
+        if (!ok) break;
+        {
+            const double rr = ring_intra<GS, E>(bufT, ncols(s_top[k]), bufB, ncols(s_bot[k]), tid, tol2, zero2);
+            ratio = rr > ratio ? rr : ratio;
+        }
+        // ---- block-wide maximum of the squared cosines this sweep SAW: one returning atomic max + one arrival per workgroup ----
+        if (tid == 0) *s_rbits = 0ull;
+        __syncthreads();
+        {
+            const unsigned long long key = wave_max_u64((unsigned long long)__double_as_longlong(ratio));
+            if (lane == 0 && key) atomicMax(s_rbits, key);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long* conv = (unsigned long long*)(A.sync + A.conv_off) + (int64_t)it.li * A.max_sweeps + sweeps;
+            unsigned* arrive = A.sync + A.arrive_off + it.li * A.max_sweeps + sweeps;
+            unsigned long long mx = *s_rbits;
+            if (P > 1) {
+                const unsigned long long old = __hip_atomic_fetch_max(conv, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the maximum has been applied before this workgroup arrives
+                (void)old;
+                __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ring_wait_ge(arrive, (unsigned)P, fail)) mx = __hip_atomic_load(conv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *s_ok = 0;
+            }
+            *s_rbits = mx;
+        }
+        __syncthreads();
+        ok = *s_ok != 0;
+        ++sweeps;
+        done = __longlong_as_double((long long)*s_rbits) <= thr;
+        __syncthreads();
+    }
+    // ---- result: column norms -> S, columns (pivoting undone) -> G; the panels are wherever the tournament left them ----
+    double2* __restrict__ g = A.G + D.g_off;
+    const int* __restrict__ pc = A.perm + it.li * 64 * JAC_MAXEL;
+    for (int side = 0; side < 2; ++side) {
+        const double2* buf = side ? bufB : bufT;
+        const int q = side ? s_bot[k] : s_top[k];
+        const int nc = ncols(q);
+        for (int c = wave; c < nc; c += RING_THREADS / 64) {
+            const int col = q * w + c;
+            double sn = 0.0;
+            for (int i = lane; i < m; i += 64) {
+                const double2 x = buf[c * mp + i];
+                sn += x.x * x.x + x.y * x.y;
+                g[(int64_t)col * m + pc[i]] = x;
+            }
+            sn = wave_sum(sn);
+            if (lane == 0) A.S[D.s_off + col] = sqrt(sn);
+        }
+    }
+    for (int col = n + k * (RING_THREADS / 64) + wave; col < D.n; col += P * (RING_THREADS / 64)) {      // columns beyond the rank: zero
+        for (int i = lane; i < m; i += 64) g[(int64_t)col * m + i] = make_double2(0.0, 0.0);
+        if (lane == 0) A.S[D.s_off + col] = 0.0;
+    }
+    if (k == 0 && tid == 0) {
+        A.info[A.large_ids[it.li]] = (done && ok) ? sweeps : -(sweeps > 0 ? sweeps : 1);
+        A.sweeps_out[it.li] = ok ? sweeps : 0;
+        __threadfence_system();
+    }
+}
+
+__global__ __launch_bounds__(RING_THREADS) void k_jacobi_ring(RingArgs A) {
+    extern __shared__ double2 g_lds[];
+    __shared__ int s_top[RING_MAX_P], s_bot[RING_MAX_P];
+    __shared__ unsigned long long s_rbits;
+    __shared__ int s_ok;
+    const RingItem it = A.items[blockIdx.x];
+    const htn_svd_block D = A.desc[A.large_ids[it.li]];
+    // lanes per column pair and elements per lane, chosen so that a lane holds <= 4 elements of a column up to 256 rows
+    // (the panels are re-padded to mpr = GS * E rows in LDS and in the mailboxes; X keeps its own leading dimension)
+    const int m = D.m;
+    const int gs = ring_gs(m), E = (m + gs - 1) / gs;
+#define RING_CASE(GSV, EV) \
+    case EV: ring_run<GSV, EV>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok); break;
+    if (gs == 16) {
+        switch (E) {
+            RING_CASE(16, 1) RING_CASE(16, 2) RING_CASE(16, 3) default: ring_run<16, 4>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok);
+        }
+    } else if (gs == 32) {           // 64 < m <= 128
+        switch (E) {
+            RING_CASE(32, 3) default: ring_run<32, 4>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok);
+        }
+    } else {                         // 128 < m <= 512
+        switch (E) {
+            RING_CASE(64, 3) RING_CASE(64, 4) RING_CASE(64, 5) RING_CASE(64, 6) RING_CASE(64, 7)
+            default: ring_run<64, 8>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok);
+        }
+    }
+#undef RING_CASE
+}
+
 // per-stream scratch of the multi-launch path (grown on demand; htn_common.h: owned by the stream's registry entry and
 // released by the backend that owns the stream)
 struct JacScratch {
@@ -1209,6 +1614,14 @@ struct JacScratch {
     int* flags = nullptr;               // device -> host: [active count per sweep | rank per large block]; coherent, its own block
     int* flags_dev = nullptr;           // device view of it
     size_t flags_elems = 0;
+    void* ring_sync = nullptr;          // ring Jacobi: flags / arrival counters / maxima (zeroed before every launch)
+    size_t ring_sync_bytes = 0;
+    void* ring_mbox = nullptr;          // ring Jacobi: mailboxes
+    size_t ring_mbox_bytes = 0;
+    void* ring_items = nullptr;         // ring Jacobi: work items (device) and their pinned staging
+    void* ring_items_h = nullptr;
+    size_t ring_items_cap = 0;
+    int cu_count = 0;
     hipStream_t aux = nullptr;          // forked stream: small blocks run beside the large-block pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sweep[2] = {nullptr, nullptr};
     ~JacScratch() {
@@ -1224,6 +1637,10 @@ struct JacScratch {
         if (dev) (void)hipFree(dev);
         if (pinned) (void)hipHostFree(pinned);
         if (flags) (void)hipHostFree(flags);
+        if (ring_sync) (void)hipFree(ring_sync);
+        if (ring_mbox) (void)hipFree(ring_mbox);
+        if (ring_items) (void)hipFree(ring_items);
+        if (ring_items_h) (void)hipHostFree(ring_items_h);
     }
 };
 static std::mutex g_js_mu;
@@ -1240,6 +1657,7 @@ static int js_get(hipStream_t st, JacScratch** out) {
     if (!slot) {
         slot = std::make_unique<JacScratch>();
         HIP_TRY(hipGetDevice(&slot->device));
+        HIP_TRY(hipDeviceGetAttribute(&slot->cu_count, hipDeviceAttributeMultiprocessorCount, slot->device));
     }
     *out = slot.get();
     return 0;
@@ -1302,6 +1720,8 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
                                         16 * (64 * JAC_MAXEL + 1) * (int)sizeof(double2)));
             HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_pairs_gram, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (16 * (64 * JAC_MAXEL + 1) + JG_GU_ELEMS) * (int)sizeof(double2)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_jacobi_ring, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        2 * RING_PANEL_ELEMS * (int)sizeof(double2)));
             attr_set[dev] = true;
         }
     }
@@ -1378,7 +1798,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     if (js_get(st, &jsp)) return 1;
     JacScratch& g_js = *jsp;
     if (js_reserve(g_js, dev_bytes, sizeof(JacPairItem) * n_items_max + 4 * (size_t)(nl + n_blocks) + 128,
-                   (size_t)(max_sweeps + 1) + (size_t)nl + 16))
+                   (size_t)(max_sweeps + 1) + 2 * (size_t)nl + 16))
         return 1;
     char* d = (char*)g_js.dev;
     int* d_ids = (int*)(d + off_ids);
@@ -1399,6 +1819,8 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     volatile int* h_rank = h_active + (max_sweeps + 1);
     int* d_active = g_js.flags_dev;
     int* d_rank = d_active + (max_sweeps + 1);
+    volatile int* h_ring_sw = h_rank + nl;           // ring path: outer sweeps per large block (0: the launch failed)
+    int* d_ring_sw = d_rank + nl;
     for (int b = 0; b < n_blocks; ++b) h_slot[b] = -1;
     for (int li = 0; li < nl; ++li) h_slot[large[li]] = li;
     for (int li = 0; li < nl; ++li) h_ids[li] = large[li];
@@ -1422,7 +1844,55 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         if (pos) HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(JacPairItem) * pos, hipMemcpyHostToDevice, st));
         return 0;
     };
-    if (cut2 <= 0.0 && upload_rounds()) return 1;
+    // Ring path (default): all sweeps of the large blocks in one launch per batch of <= #CU workgroups.  The multi-launch
+    // pair-visit path stays for blocks the ring cannot take (more CU slots than the chip has) and behind HTN_SVD_PAIRS=1.
+    static const bool force_pairs = htn_env_flag("HTN_SVD_PAIRS");
+    std::vector<RingItem> ring_items;
+    std::vector<std::pair<int, int>> ring_batches;            // (first workgroup, count) of each launch
+    int64_t ring_mbox_elems = 0;
+    const int ring_cap = std::max(1, std::min(g_js.cu_count > 0 ? g_js.cu_count : 256, 256));
+    // CU slots and panel width of every large block; batches of <= #CU workgroups (all workgroups of a launch must be
+    // co-resident: they wait for each other).  false: some block needs more slots than the ring supports.
+    auto plan_ring = [&]() -> bool {
+        ring_items.clear();
+        ring_batches.clear();
+        ring_mbox_elems = 0;
+        struct Blk {
+            int li, P, w, mp;
+        };
+        std::vector<Blk> blks;
+        for (int li = 0; li < nl; ++li) {
+            const htn_svd_block& D = desc_host[large[li]];
+            const int gsx = ring_gs(D.m);
+            const int mp = gsx * ((D.m + gsx - 1) / gsx);
+            int wcap = std::min(RING_THREADS / gsx, RING_PANEL_ELEMS / mp);
+            if (g_jac_split > 0) wcap = std::min(wcap, 3);       // test mode: small blocks still get several CU slots
+            const int n = std::max(n_eff[li], 1);
+            const int P = std::max(1, (n + 2 * wcap - 1) / (2 * wcap));
+            if (wcap < 1 || P > RING_MAX_P || P > ring_cap) return false;
+            blks.push_back({li, P, (n + 2 * P - 1) / (2 * P), mp});
+        }
+        std::stable_sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) { return a.P > b.P; });
+        std::vector<char> placed(blks.size(), 0);
+        size_t left = blks.size();
+        while (left) {
+            const int first = (int)ring_items.size();
+            int used = 0;
+            for (size_t q = 0; q < blks.size(); ++q) {
+                if (placed[q] || used + blks[q].P > ring_cap) continue;
+                const Blk& B = blks[q];
+                for (int k = 0; k < B.P; ++k) ring_items.push_back({B.li, k, B.P, B.w, n_eff[B.li], first + used, ring_mbox_elems});
+                ring_mbox_elems += (int64_t)B.P * 4 * B.w * B.mp;
+                used += B.P;
+                placed[q] = 1;
+                --left;
+            }
+            ring_batches.push_back({first, used});
+        }
+        return true;
+    };
+    bool use_ring = !force_pairs && plan_ring();
+    if (cut2 <= 0.0 && !use_ring && upload_rounds()) return 1;
     // large blocks: pivoted QR on this stream, then the sweeps; the small blocks run their whole SVD beside
     // them on the forked stream and join before the call returns
     HIP_TRY(hipEventRecord(g_js.ev_fork, st));
@@ -1442,7 +1912,61 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         HIP_TRY(hipEventRecord(g_js.ev_sweep[0], st));
         HIP_TRY(htn_event_spin(g_js.ev_sweep[0]));
         for (int li = 0; li < nl; ++li) n_eff[li] = std::min(n_eff[li], (int)h_rank[li]);
-        if (upload_rounds()) return 1;
+        if (use_ring) use_ring = plan_ring();
+        if (!use_ring && upload_rounds()) return 1;
+    }
+    if (use_ring) {
+        const int n_wg = (int)ring_items.size();
+        // sync block (32-bit words): [flags: 2 per workgroup | arrivals: nl x max_sweeps | failure word | pad] then the
+        // 64-bit maxima, nl x max_sweeps; zeroed as ONE block that starts its allocation and is a multiple of 16 bytes
+        const int arrive_off = 2 * n_wg, fail_off = arrive_off + nl * max_sweeps;
+        const int conv_off = (fail_off + 1 + 3) & ~3;
+        const size_t sync_bytes = ((size_t)conv_off * 4 + (size_t)nl * max_sweeps * 8 + 15) & ~(size_t)15;
+        if (sync_bytes > g_js.ring_sync_bytes) {
+            if (g_js.ring_sync) HIP_TRY(hipFree(g_js.ring_sync));
+            g_js.ring_sync = nullptr, g_js.ring_sync_bytes = 0;
+            HIP_TRY(hipMalloc(&g_js.ring_sync, sync_bytes * 2));
+            g_js.ring_sync_bytes = sync_bytes * 2;
+        }
+        const size_t mbox_bytes = sizeof(double2) * (size_t)std::max<int64_t>(ring_mbox_elems, 1);
+        if (mbox_bytes > g_js.ring_mbox_bytes) {
+            if (g_js.ring_mbox) HIP_TRY(hipFree(g_js.ring_mbox));
+            g_js.ring_mbox = nullptr, g_js.ring_mbox_bytes = 0;
+            HIP_TRY(hipMalloc(&g_js.ring_mbox, mbox_bytes + mbox_bytes / 2));
+            g_js.ring_mbox_bytes = mbox_bytes + mbox_bytes / 2;
+            if (htn_debug_poison()) HIP_TRY(hipMemset(g_js.ring_mbox, 0xFF, g_js.ring_mbox_bytes));
+        }
+        if ((size_t)n_wg > g_js.ring_items_cap) {
+            if (g_js.ring_items) HIP_TRY(hipFree(g_js.ring_items));
+            if (g_js.ring_items_h) HIP_TRY(hipHostFree(g_js.ring_items_h));
+            g_js.ring_items = g_js.ring_items_h = nullptr, g_js.ring_items_cap = 0;
+            HIP_TRY(hipMalloc(&g_js.ring_items, sizeof(RingItem) * 2 * n_wg));
+            HIP_TRY(hipHostMalloc(&g_js.ring_items_h, sizeof(RingItem) * 2 * n_wg, hipHostMallocDefault));
+            g_js.ring_items_cap = 2 * (size_t)n_wg;
+        }
+        memcpy(g_js.ring_items_h, ring_items.data(), sizeof(RingItem) * n_wg);
+        for (int li = 0; li < nl; ++li) h_ring_sw[li] = 0;
+        HIP_TRY(hipMemcpyAsync(g_js.ring_items, g_js.ring_items_h, sizeof(RingItem) * n_wg, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(g_js.ring_sync, 0, sync_bytes, st));
+        RingArgs ra;
+        ra.Vj = (double2*)Vj, ra.G = (double2*)G, ra.S = S, ra.desc = desc, ra.large_ids = d_ids;
+        ra.perm = d_perm, ra.zero2 = d_zero, ra.mbox = (double2*)g_js.ring_mbox, ra.sync = (unsigned*)g_js.ring_sync;
+        ra.arrive_off = arrive_off, ra.fail_off = fail_off, ra.conv_off = conv_off, ra.max_sweeps = max_sweeps, ra.tol = tol;
+        ra.info = info_dev, ra.sweeps_out = d_ring_sw;
+        for (auto& bt : ring_batches) {
+            ra.items = (const RingItem*)g_js.ring_items + bt.first;
+            hipLaunchKernelGGL(k_jacobi_ring, dim3((unsigned)bt.second), dim3(RING_THREADS), 2 * RING_PANEL_ELEMS * sizeof(double2), st, ra);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamWaitEvent(st, g_js.ev_join, 0));
+        HIP_TRY(htn_stream_spin(st));      // the staging blocks are reused by the next call; the sweep counts are read below
+        int used = 0;
+        for (int li = 0; li < nl; ++li) {
+            if (h_ring_sw[li] <= 0 && n_eff[li] >= 2) return fail_msg("htn_jacobi_svd_z: a hand-off of the ring Jacobi kernel timed out");
+            used = std::max(used, (int)h_ring_sw[li]);
+        }
+        if (opts && opts->sweeps_used) *opts->sweeps_used = used;
+        return 0;
     }
     const size_t gram_lds_bytes = (size_t)(16 * (max_mp + 1) + JG_GU_ELEMS) * sizeof(double2);
     // sweeps are enqueued one ahead of the host's knowledge (depth-1 pipeline, like htn_lanczos_z): the device
