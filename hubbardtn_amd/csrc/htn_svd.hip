@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_finish(double2* __restri
 // every round, so a sender can be at most one round ahead of its receiver and never overwrites a slot that is still unread.
 // All workgroups of a launch are co-resident (the host caps the grid at the CU count; LDS use forces one per CU); every poll
 // is bounded by wall-clock time and a shared failure word, so a launch always drains.
-#define RING_THREADS 1024
+#define RING_THREADS 512
 #define RING_PANEL_ELEMS 4608         // complex128 elements of one resident panel (2 panels = 144 KiB of LDS)
 #define RING_MAX_P 64
 struct RingItem {
@@ -1233,7 +1233,15 @@ struct RingItem {
     int64_t mbox;      // element offset of the block's mailboxes: slot k owns 4 slots [role][parity] of w * mp elements
 };                     // 32 bytes
 typedef unsigned int ring_u4 __attribute__((ext_vector_type(4)));
-__host__ __device__ __forceinline__ int ring_gs(int m) { return m <= 64 ? 16 : (m <= 128 ? 32 : 64); }
+// lanes per column (GS) and elements per lane (E, even): up to 256 rows ONE 16-lane row holds a column, so the four sums of
+// a rotation are DPP butterflies inside the row with no cross-row stage, a wave rotates four pairs at once and the reductions
+// and the scalar arithmetic of a rotation are amortised over 16 elements per lane (the first version used 64 lanes x 4
+// elements: 260 wave instructions per pair, 64 of them useful; measured 1.9 us per step of 15 pairs, VALU-issue bound)
+__host__ __device__ __forceinline__ int ring_gs(int m) { return m <= 256 ? 16 : 32; }
+__host__ __device__ __forceinline__ int ring_e(int m) {
+    const int g2 = 2 * ring_gs(m);
+    return 2 * ((m + g2 - 1) / g2);
+}
 
 // one lane polls one word (relaxed, agent scope); false: timed out or another workgroup reported failure
 __device__ __forceinline__ bool ring_wait_ge(unsigned* flag, unsigned want, unsigned* fail) {
@@ -1261,16 +1269,22 @@ __device__ __forceinline__ void ring_send(const double2* __restrict__ src, doubl
         __builtin_amdgcn_raw_buffer_store_b128(u, rs, idx * 16, 0, 16);       // aux 16 = sc1
     }
 }
-// mailbox slot -> LDS panel, every load sc1; all loads of a thread in flight together (cnt <= 5 * 1024)
+// mailbox slot -> LDS panel, every load sc1; all loads of a thread in flight together (cnt <= 9 * 512)
 __device__ __forceinline__ void ring_recv(double2* dst, const double2* slot, int cnt, int tid) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slot, 0, cnt * 16, 0x00020000);
     // (unconditional loads: the descriptor's range check returns zeros beyond cnt, and a conditionally filled register
     // array makes the compiler carry -- and spill -- the whole array as one tuple)
-    const ring_u4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 0 * RING_THREADS) * 16, 0, 16);
-    const ring_u4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 1 * RING_THREADS) * 16, 0, 16);
-    const ring_u4 u2 = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 2 * RING_THREADS) * 16, 0, 16);
-    const ring_u4 u3 = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 3 * RING_THREADS) * 16, 0, 16);
-    const ring_u4 u4 = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 4 * RING_THREADS) * 16, 0, 16);
+#define RING_LD(q) const ring_u4 u##q = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + q * RING_THREADS) * 16, 0, 16)
+    RING_LD(0);
+    RING_LD(1);
+    RING_LD(2);
+    RING_LD(3);
+    RING_LD(4);
+    RING_LD(5);
+    RING_LD(6);
+    RING_LD(7);
+    RING_LD(8);
+#undef RING_LD
     auto put = [&](int idx, ring_u4 u) {
         if (idx < cnt) {
             double2 v;
@@ -1283,55 +1297,80 @@ __device__ __forceinline__ void ring_recv(double2* dst, const double2* slot, int
     put(tid + 2 * RING_THREADS, u2);
     put(tid + 3 * RING_THREADS, u3);
     put(tid + 4 * RING_THREADS, u4);
+    put(tid + 5 * RING_THREADS, u5);
+    put(tid + 6 * RING_THREADS, u6);
+    put(tid + 7 * RING_THREADS, u7);
+    put(tid + 8 * RING_THREADS, u8);
 }
 
-// rotation of a column pair held in registers (the arithmetic of jacobi_pair_pad); returns the squared cosine seen
-template <int GS, int E>
-__device__ __forceinline__ double ring_rotate(double2 (&a)[E], double2 (&b)[E], double tol2, double zero2) {
-    double aa = 0.0, bb = 0.0, gr = 0.0, gi = 0.0;
+// Rotation of a column pair held in registers; returns the squared cosine seen.  With g = a^H b, h = |b|^2 - |a|^2:
+//   q = sign(h) 2 / (|h| + sqrt(h^2 + 4 |g|^2)) = tan / |g|,  c = 1 / sqrt(1 + q^2 |g|^2),
+//   [a' b'] = [a b] [[c, c q g], [-c q conj(g), c]]
+// -- real diagonal, so neither |g| nor the phase g / |g| is ever formed (three reciprocal-type operations instead of
+// five); against the textbook form b' carries an extra unit phase, which a one-sided Jacobi SVD is free to choose.
+// NORMS = false: aa / bb come in as the tracked squared norms of the two columns and go out updated by Rutishauser's
+// identities |a'|^2 = |a|^2 - q |g|^2, |b'|^2 = |b|^2 + q |g|^2 (as LAPACK's xGESVJ tracks them); they only steer the
+// rotation angle and the stopping test and are recomputed from the columns at the start of every round, i.e. after at
+// most w updates.  Halves the dot products and the reductions of a rotation.
+template <int GS, int E, bool NORMS>
+__device__ __forceinline__ double ring_rotate(double2 (&a)[E], const double2 (&b)[E], double2* b_out, double& aa, double& bb,
+                                              double tol2, double zero2) {
+    double gr = 0.0, gi = 0.0;
+    if (NORMS) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            sa = fma(a[e].x, a[e].x, fma(a[e].y, a[e].y, sa));
+            sb = fma(b[e].x, b[e].x, fma(b[e].y, b[e].y, sb));
+        }
+        aa = group_sum<GS>(sa);
+        bb = group_sum<GS>(sb);
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        aa = fma(a[e].x, a[e].x, fma(a[e].y, a[e].y, aa));
-        bb = fma(b[e].x, b[e].x, fma(b[e].y, b[e].y, bb));
         gr = fma(a[e].x, b[e].x, fma(a[e].y, b[e].y, gr));      // conj(a) * b
         gi = fma(a[e].x, b[e].y, fma(-a[e].y, b[e].x, gi));
     }
-    aa = group_sum<GS>(aa);
-    bb = group_sum<GS>(bb);
     gr = group_sum<GS>(gr);
     gi = group_sum<GS>(gi);
     if (aa <= zero2 || bb <= zero2) return 0.0;
-    const double g2 = gr * gr + gi * gi;
+    const double g2 = fma(gr, gr, gi * gi);
     const double ab = aa * bb;
-    const double ratio2 = g2 * fast_rcp(ab);
-    if (g2 == 0.0 || g2 <= tol2 * ab) return ratio2;
-    const double ig = fast_rsq(g2);
-    const double g = g2 * ig;
+    if (g2 == 0.0) return 0.0;
+    // the squared cosine only steers the stopping test: the hardware reciprocal (no Newton step) is plenty
+    const double ratio2 = g2 * __builtin_amdgcn_rcp(ab);
+    if (g2 <= tol2 * ab) return ratio2;
     const double h = bb - aa;
     const double w2 = fma(h, h, 4.0 * g2);
     const double w = w2 * fast_rsq(w2);
-    double t = 2.0 * g * fast_rcp(fabs(h) + w);
-    t = h >= 0.0 ? t : -t;
-    const double c = fast_rsq(fma(t, t, 1.0));
-    const double s = c * t;
-    const double sr = s * gr * ig, si = -s * gi * ig;           // sig = s exp(-i phi), tau = c exp(-i phi)
-    const double tr = c * gr * ig, ti = -c * gi * ig;
+    double q = 2.0 * fast_rcp(fabs(h) + w);
+    q = h >= 0.0 ? q : -q;
+    const double c = fast_rsq(fma(q * q, g2, 1.0));
+    const double cq = c * q;
+    const double sr = cq * gr, si = -cq * gi;                   // sig = c q conj(g):  a' = c a - sig b,  b' = conj(sig) a + c b
+    aa = fma(-q, g2, aa);
+    bb = fma(q, g2, bb);
+    // b' goes straight to its column in LDS (only a rotated column is written back), a is updated IN PLACE (scale, then
+    // accumulate): neither needs a register copy where the rotated and the skipped path meet
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        double2 na, nb;
-        na.x = fma(c, a[e].x, fma(-sr, b[e].x, si * b[e].y));
-        na.y = fma(c, a[e].y, fma(-sr, b[e].y, -si * b[e].x));
-        nb.x = fma(s, a[e].x, fma(tr, b[e].x, -ti * b[e].y));
-        nb.y = fma(s, a[e].y, fma(tr, b[e].y, ti * b[e].x));
-        a[e] = na;
-        b[e] = nb;
+        double2 nb;
+        nb.x = fma(si, a[e].y, fma(sr, a[e].x, c * b[e].x));
+        nb.y = fma(-si, a[e].x, fma(sr, a[e].y, c * b[e].y));
+        b_out[GS * e] = nb;
+        double x = a[e].x * c, y = a[e].y * c;
+        x = fma(-sr, b[e].x, x);
+        y = fma(-sr, b[e].y, y);
+        a[e].x = fma(si, b[e].y, x);
+        a[e].y = fma(-si, b[e].x, y);
     }
     return ratio2;
 }
 
-// all nt x nb cross pairs of the two resident panels: group g owns T column g in registers, B columns pass through LDS
+// all nt x nb cross pairs of the two resident panels: group g owns T column g in registers (and its tracked norm), B columns
+// pass through LDS, their tracked norms through bnorm[]
 template <int GS, int E>
-__device__ __forceinline__ double ring_cross(double2* T, double2* B, int nt, int nb, int tid, double tol2, double zero2) {
+__device__ __forceinline__ double ring_cross(double2* T, double2* B, int nt, int nb, int tid, double tol2, double zero2, double* bnorm) {
     constexpr int mp = GS * E;
     const int grp = tid / GS, sub = tid % GS;
     const int wm = nt > nb ? nt : nb;
@@ -1339,10 +1378,27 @@ __device__ __forceinline__ double ring_cross(double2* T, double2* B, int nt, int
     if (nt == 0 || nb == 0) return ratio;                      // (uniform over the workgroup)
     const bool own = grp < nt;
     double2 a[E];
+    double aa = 0.0;
     if (own) {
 #pragma unroll
         for (int e = 0; e < E; ++e) a[e] = T[grp * mp + sub + GS * e];
+        double sa = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) sa = fma(a[e].x, a[e].x, fma(a[e].y, a[e].y, sa));
+        aa = group_sum<GS>(sa);
     }
+    if (grp < nb) {            // exact squared norm of B column grp
+        const double2* bc = B + grp * mp + sub;
+        double sb = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double2 v = bc[GS * e];
+            sb = fma(v.x, v.x, fma(v.y, v.y, sb));
+        }
+        sb = group_sum<GS>(sb);
+        if (sub == 0) bnorm[grp] = sb;
+    }
+    __syncthreads();
     for (int s = 0; s < wm; ++s) {
         int j = grp + s;
         j = j >= wm ? j - wm : j;
@@ -1351,10 +1407,10 @@ __device__ __forceinline__ double ring_cross(double2* T, double2* B, int nt, int
             double2* bc = B + j * mp + sub;
 #pragma unroll
             for (int e = 0; e < E; ++e) b[e] = bc[GS * e];
-            const double rr = ring_rotate<GS, E>(a, b, tol2, zero2);
+            double bb = bnorm[j];
+            const double rr = ring_rotate<GS, E, false>(a, b, bc, aa, bb, tol2, zero2);
             ratio = rr > ratio ? rr : ratio;
-#pragma unroll
-            for (int e = 0; e < E; ++e) bc[GS * e] = b[e];
+            if (sub == 0) bnorm[j] = bb;
         }
         __syncthreads();
     }
@@ -1400,6 +1456,19 @@ __device__ __forceinline__ double ring_intra(double2* T, int nt, double2* B, int
     return ratio;
 }
 
+#ifdef HTN_RING_PROF        // diagnostic build only (tools/ring_prof.py): per-workgroup 100 MHz tick sums per phase
+__device__ long long g_ring_prof[256 * 8];
+extern "C" int htn_ring_prof_dump(long long* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_prof), sizeof(long long) * 256 * 8));
+    return 0;
+}
+#define RING_T(var) const long long var = wall_clock64()
+#define RING_ACC(slot, a, b) prof[slot] += (b) - (a)
+#else
+#define RING_T(var)
+#define RING_ACC(slot, a, b)
+#endif
 struct RingArgs {
     double2* Vj;
     double2* G;
@@ -1420,7 +1489,7 @@ struct RingArgs {
 
 template <int GS, int E>
 __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, const htn_svd_block D, double2* lds, int* s_top, int* s_bot,
-                         unsigned long long* s_rbits, int* s_ok) {
+                         unsigned long long* s_rbits, int* s_ok, double* s_bnorm) {
     constexpr int mp = GS * E;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = it.P, k = it.k, w = it.w, n = it.n, m = D.m;
@@ -1457,6 +1526,10 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
         }
     }
     __syncthreads();
+#ifdef HTN_RING_PROF
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // cross | send+drain | flags+wait | recv | intra | conv | total | sweeps
+    const long long prof_t0 = wall_clock64();
+#endif
     int sweeps = 0;
     bool done = n < 2, ok = true;
     const int rounds = 2 * P - 1;
@@ -1466,8 +1539,11 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
             const unsigned epoch = (unsigned)(sweeps * rounds + r + 1);
             const int par = (int)(epoch & 1u);
             const int nt = ncols(s_top[k]), nb = ncols(s_bot[k]);
-            const double rr = ring_cross<GS, E>(bufT, bufB, nt, nb, tid, tol2, zero2);
+            RING_T(p0);
+            const double rr = ring_cross<GS, E>(bufT, bufB, nt, nb, tid, tol2, zero2, s_bnorm);
             ratio = rr > ratio ? rr : ratio;
+            RING_T(p1);
+            RING_ACC(0, p0, p1);
             if (P < 2) continue;
             // ---- panels move one position: send, drain, raise the flags ----
             double2* box = A.mbox + it.mbox;                    // slot of workgroup kd, role, parity: ((kd * 2 + role) * 2 + par)
@@ -1478,6 +1554,8 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            RING_T(p2);
+            RING_ACC(1, p1, p2);
             if (tid == 0) {
                 if (k == 0) __hip_atomic_store(flags + (it.g0 + 1) * 2 + 0, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else {
@@ -1502,6 +1580,8 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
                 bufB = t;
             }
             __syncthreads();
+            RING_T(p3);
+            RING_ACC(2, p2, p3);
             ok = *s_ok != 0;
             if (ok) {
                 const double2* mine = box + (int64_t)(k * 4) * slot_elems;
@@ -1509,12 +1589,17 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
                 if (k < P - 1) ring_recv(bufB, mine + (int64_t)(1 * 2 + par) * slot_elems, ncols(s_bot[k]) * mp, tid);
             }
             __syncthreads();
+            RING_T(p4);
+            RING_ACC(3, p3, p4);
         }
         if (!ok) break;
+        RING_T(p5);
         {
             const double rr = ring_intra<GS, E>(bufT, ncols(s_top[k]), bufB, ncols(s_bot[k]), tid, tol2, zero2);
             ratio = rr > ratio ? rr : ratio;
         }
+        RING_T(p6);
+        RING_ACC(4, p5, p6);
         // ---- block-wide maximum of the squared cosines this sweep SAW: one returning atomic max + one arrival per workgroup ----
         if (tid == 0) *s_rbits = 0ull;
         __syncthreads();
@@ -1542,7 +1627,16 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
         ++sweeps;
         done = __longlong_as_double((long long)*s_rbits) <= thr;
         __syncthreads();
+        RING_T(p7);
+        RING_ACC(5, p6, p7);
     }
+#ifdef HTN_RING_PROF
+    if (tid == 0 && blockIdx.x < 256) {
+        prof[6] = wall_clock64() - prof_t0;
+        prof[7] = sweeps * 1000 + P;
+        for (int q = 0; q < 8; ++q) g_ring_prof[blockIdx.x * 8 + q] = prof[q];
+    }
+#endif
     // ---- result: column norms -> S, columns (pivoting undone) -> G; the panels are wherever the tournament left them ----
     double2* __restrict__ g = A.G + D.g_off;
     const int* __restrict__ pc = A.perm + it.li * 64 * JAC_MAXEL;
@@ -1578,26 +1672,22 @@ __global__ __launch_bounds__(RING_THREADS) void k_jacobi_ring(RingArgs A) {
     __shared__ int s_top[RING_MAX_P], s_bot[RING_MAX_P];
     __shared__ unsigned long long s_rbits;
     __shared__ int s_ok;
+    __shared__ double s_bnorm[RING_THREADS / 16];
     const RingItem it = A.items[blockIdx.x];
     const htn_svd_block D = A.desc[A.large_ids[it.li]];
-    // lanes per column pair and elements per lane, chosen so that a lane holds <= 4 elements of a column up to 256 rows
-    // (the panels are re-padded to mpr = GS * E rows in LDS and in the mailboxes; X keeps its own leading dimension)
     const int m = D.m;
-    const int gs = ring_gs(m), E = (m + gs - 1) / gs;
+    const int gs = ring_gs(m), E = ring_e(m);
 #define RING_CASE(GSV, EV) \
-    case EV: ring_run<GSV, EV>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok); break;
-    if (gs == 16) {
+    case EV: ring_run<GSV, EV>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm); break;
+    if (gs == 16) {                  // m <= 256
         switch (E) {
-            RING_CASE(16, 1) RING_CASE(16, 2) RING_CASE(16, 3) default: ring_run<16, 4>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok);
+            RING_CASE(16, 2) RING_CASE(16, 4) RING_CASE(16, 6) RING_CASE(16, 8) RING_CASE(16, 10) RING_CASE(16, 12) RING_CASE(16, 14)
+            default: ring_run<16, 16>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm);
         }
-    } else if (gs == 32) {           // 64 < m <= 128
+    } else {                         // 256 < m <= 512: E = 10 .. 16
         switch (E) {
-            RING_CASE(32, 3) default: ring_run<32, 4>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok);
-        }
-    } else {                         // 128 < m <= 512
-        switch (E) {
-            RING_CASE(64, 3) RING_CASE(64, 4) RING_CASE(64, 5) RING_CASE(64, 6) RING_CASE(64, 7)
-            default: ring_run<64, 8>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok);
+            RING_CASE(32, 10) RING_CASE(32, 12) RING_CASE(32, 14)
+            default: ring_run<32, 16>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm);
         }
     }
 #undef RING_CASE
@@ -1864,8 +1954,9 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         for (int li = 0; li < nl; ++li) {
             const htn_svd_block& D = desc_host[large[li]];
             const int gsx = ring_gs(D.m);
-            const int mp = gsx * ((D.m + gsx - 1) / gsx);
+            const int mp = gsx * ring_e(D.m);
             int wcap = std::min(RING_THREADS / gsx, RING_PANEL_ELEMS / mp);
+            if (gsx == 16 && wcap > 16 && wcap < 32) wcap = 16;      // 16 pairs = one busy wave per SIMD; 17..31 would put two on one
             if (g_jac_split > 0) wcap = std::min(wcap, 3);       // test mode: small blocks still get several CU slots
             const int n = std::max(n_eff[li], 1);
             const int P = std::max(1, (n + 2 * wcap - 1) / (2 * wcap));
