@@ -1233,16 +1233,18 @@ struct RingItem {
     int64_t mbox;      // element offset of the block's mailboxes: slot k owns 4 slots [role][parity] of w * mp elements
 };                     // 32 bytes
 typedef unsigned int ring_u4 __attribute__((ext_vector_type(4)));
-// lanes per column (GS) and elements per lane (E, even): up to 256 rows ONE 16-lane row holds a column, so the four sums of
-// a rotation are DPP butterflies inside the row with no cross-row stage, a wave rotates four pairs at once and the reductions
-// and the scalar arithmetic of a rotation are amortised over 16 elements per lane (the first version used 64 lanes x 4
-// elements: 260 wave instructions per pair, 64 of them useful; measured 1.9 us per step of 15 pairs, VALU-issue bound)
-__host__ __device__ __forceinline__ int ring_gs(int m) { return m <= 256 ? 16 : 32; }
+// Lanes per column (GS) and elements per lane (E).  A rotation step is a dependent chain (LDS read -> dots -> DPP sums ->
+// rotation arithmetic -> update -> LDS write -> barrier) and every VALU instruction of a wave costs 4 clocks whatever it does,
+// so the sums and the scalar arithmetic of a rotation must be amortised over many elements per lane.  Measured per step of
+// 15-16 pairs on a 202 x 202 block: 64 lanes x 4 elements (one pair per wave, 16 waves) 1.86 us -- 260 wave instructions per
+// pair, 64 of them useful, VALU-issue bound; 16 lanes x 14 elements (FOUR pairs per wave, the sums stay inside one DPP row)
+// 1.06 us; 32 lanes x 7 elements (two pairs per wave, two busy waves per SIMD) 1.12 us.  Beyond 256 rows a lane cannot hold
+// a column in 16 lanes' registers: 64 lanes x <= 8 elements.
+__host__ __device__ __forceinline__ int ring_gs(int m) { return m <= 256 ? 16 : 64; }
 __host__ __device__ __forceinline__ int ring_e(int m) {
-    const int g2 = 2 * ring_gs(m);
-    return 2 * ((m + g2 - 1) / g2);
+    const int g = ring_gs(m);
+    return (m + g - 1) / g;
 }
-
 // one lane polls one word (relaxed, agent scope); false: timed out or another workgroup reported failure
 __device__ __forceinline__ bool ring_wait_ge(unsigned* flag, unsigned want, unsigned* fail) {
     const long long t0 = wall_clock64();
@@ -1340,10 +1342,13 @@ __device__ __forceinline__ double ring_rotate(double2 (&a)[E], const double2 (&b
     // the squared cosine only steers the stopping test: the hardware reciprocal (no Newton step) is plenty
     const double ratio2 = g2 * __builtin_amdgcn_rcp(ab);
     if (g2 <= tol2 * ab) return ratio2;
+    // ANY real q gives an exactly unitary rotation once c = 1 / sqrt(1 + q^2 |g|^2) is accurate; q itself only sets the
+    // angle, so the hardware rsq / rcp seeds (relative error ~1e-8: the pair is left with a cosine 1e-8 times the one it
+    // had, below what the next sweep's quadratic convergence leaves anyway) do without their Newton steps
     const double h = bb - aa;
     const double w2 = fma(h, h, 4.0 * g2);
-    const double w = w2 * fast_rsq(w2);
-    double q = 2.0 * fast_rcp(fabs(h) + w);
+    const double w = w2 * __builtin_amdgcn_rsq(w2);
+    double q = 2.0 * __builtin_amdgcn_rcp(fabs(h) + w);
     q = h >= 0.0 ? q : -q;
     const double c = fast_rsq(fma(q * q, g2, 1.0));
     const double cq = c * q;
@@ -1672,7 +1677,7 @@ __global__ __launch_bounds__(RING_THREADS) void k_jacobi_ring(RingArgs A) {
     __shared__ int s_top[RING_MAX_P], s_bot[RING_MAX_P];
     __shared__ unsigned long long s_rbits;
     __shared__ int s_ok;
-    __shared__ double s_bnorm[RING_THREADS / 16];
+    __shared__ double s_bnorm[RING_THREADS / 16];      // tracked squared norms of the bottom panel's columns
     const RingItem it = A.items[blockIdx.x];
     const htn_svd_block D = A.desc[A.large_ids[it.li]];
     const int m = D.m;
@@ -1681,13 +1686,15 @@ __global__ __launch_bounds__(RING_THREADS) void k_jacobi_ring(RingArgs A) {
     case EV: ring_run<GSV, EV>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm); break;
     if (gs == 16) {                  // m <= 256
         switch (E) {
-            RING_CASE(16, 2) RING_CASE(16, 4) RING_CASE(16, 6) RING_CASE(16, 8) RING_CASE(16, 10) RING_CASE(16, 12) RING_CASE(16, 14)
+            RING_CASE(16, 1) RING_CASE(16, 2) RING_CASE(16, 3) RING_CASE(16, 4) RING_CASE(16, 5) RING_CASE(16, 6) RING_CASE(16, 7)
+            RING_CASE(16, 8) RING_CASE(16, 9) RING_CASE(16, 10) RING_CASE(16, 11) RING_CASE(16, 12) RING_CASE(16, 13)
+            RING_CASE(16, 14) RING_CASE(16, 15)
             default: ring_run<16, 16>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm);
         }
-    } else {                         // 256 < m <= 512: E = 10 .. 16
+    } else {                         // 256 < m <= 512: E = 5 .. 8
         switch (E) {
-            RING_CASE(32, 10) RING_CASE(32, 12) RING_CASE(32, 14)
-            default: ring_run<32, 16>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm);
+            RING_CASE(64, 5) RING_CASE(64, 6) RING_CASE(64, 7)
+            default: ring_run<64, 8>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm);
         }
     }
 #undef RING_CASE

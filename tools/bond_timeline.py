@@ -10,9 +10,10 @@ qr = [i for i, r in enumerate(rows) if name(r).startswith("k_qr_large")]
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 i0, i1 = qr[-skip - 1], qr[-skip]
 t0 = int(rows[i0]["Start_Timestamp"])
-# start the window at the first Lanczos kernel after the previous SVD: walk back from i0 to the previous k_jacobi_finish
-j = i0
-while j > 0 and not name(rows[j]).startswith("k_jacobi_finish"):
+# start the window at the first Lanczos kernel after the previous SVD: walk back from i0 to the end of the previous SVD
+# (k_jacobi_ring; k_jacobi_finish on the multi-launch path)
+j = i0 - 1
+while j > 0 and not (name(rows[j]).startswith("k_jacobi_finish") or name(rows[j]).startswith("k_jacobi_ring")):
     j -= 1
 seq = rows[j:i1]
 t_base = int(seq[0]["Start_Timestamp"])
