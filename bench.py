@@ -73,21 +73,34 @@ def self_launch(args):
     sys.exit(p.returncode)
 
 
-def host_cores():
-    """host cores this process may really use: affinity mask, capped by the cgroup CPU quota; $HTN_CPU_THREADS overrides.
-    A one-GPU box of this pool exposes every core of the host in the mask but grants a 16-core share: a team of 256
-    OpenMP threads on it is throttled to a crawl (measured: 9 edge-bond updates in 50 s), so an uncapped mask wider
-    than 32 is read as that 16-core share."""
-    if os.environ.get("HTN_CPU_THREADS"):
-        return max(1, int(os.environ["HTN_CPU_THREADS"]))
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+def host_cores_info():
+    """host cores this process may really use, and how that number was arrived at: affinity mask, capped by the cgroup CPU
+    quota; $HTN_CPU_THREADS overrides.  A one-GPU box of this pool exposes every core of the host in the mask and sets no
+    quota, but grants a 16-core share: a team of 256 OpenMP threads on it is throttled to a crawl (measured: 9 edge-bond
+    updates in 50 s), so an uncapped mask wider than 32 is READ AS that 16-core share -- a rule, not a measurement, and the
+    bench line says so."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
     try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(period)
     except Exception:
         pass
-    return 16 if n > 32 else n
+    info = {"affinity_cpus": aff, "cgroup_cpu_max": quota}
+    if os.environ.get("HTN_CPU_THREADS"):
+        info.update(cores=max(1, int(os.environ["HTN_CPU_THREADS"])), rule="HTN_CPU_THREADS")
+        return info
+    n = aff if quota is None else min(aff, max(1, int(quota)))
+    if n > 32:
+        info.update(cores=16, rule="affinity mask wider than 32 and no cgroup quota: taken as the pool's 16-core share of a one-GPU box (assumed, not measured)")
+    else:
+        info.update(cores=n, rule="min(affinity mask, cgroup cpu.max quota)")
+    return info
+
+
+def host_cores():
+    return host_cores_info()["cores"]
 
 
 def cpu_baseline(eng_gpu, mpo_sites, opts, budget, log):
@@ -97,7 +110,8 @@ def cpu_baseline(eng_gpu, mpo_sites, opts, budget, log):
     from cpu_ops import CpuOps                    # context provider of oracle/cpu_backend (checker / baseline only)
     from hubbardtn_amd import engine, storage
     from oracle.cpu_backend import build as cpu_build
-    ncores = host_cores()
+    cinfo = host_cores_info()
+    ncores = cinfo["cores"]
     lap = cpu_build.lapack_path()
     ops = CpuOps(lapack=True)
     ops.set_threads(ncores)                       # (torch's OpenMP runtime is already in the process: the env var is too late)
@@ -122,6 +136,7 @@ def cpu_baseline(eng_gpu, mpo_sites, opts, budget, log):
     value = dt if done == len(order) else dt * total / max(part, 1)
     log(f"cpu baseline: {done}/{len(order)} bond updates in {dt:.1f}s on {ncores} cores -> {value:.1f} s/sweep, E={st[-1].energy:.10f}")
     return {"value": value, "unit": "s", "cores": ncores, "kind": "port",
+            "cores_rule": cinfo["rule"], "affinity_cpus": cinfo["affinity_cpus"], "cgroup_cpu_max": cinfo["cgroup_cpu_max"],
             "blas": (os.path.basename(lap) + " (LAPACKE zgesvd per block, 1 BLAS thread per task)") if lap else "built-in one-sided Jacobi",
             "threads": ncores, "dtype": "c128",
             "energy_last_bond": st[-1].energy,
@@ -275,12 +290,32 @@ def main():
                      "flop_per_launch": (k_fl / world / k_n) if k_n else None,
                      "share_of_sweep_time": (k_ms * 1e-3 / args.steps) / sweep_s if sweep_s > 0 else None},
     }
-    # HBM traffic per launch comes from offline rocprofv3 PMC passes (counters cannot be read live); see
-    # profiles/pmc_traffic.json for how it was collected and corrected
+    # Sweep-level roofline as SURVEY 8(d) defines it: sum over the bond updates of the stage bounds, divided by the sweep
+    # time.  Per bond: H_eff applies n_matvec x max(F / peak_f64, B / peak_hbm); Lanczos vector algebra 16 |theta| (2 j + 4)
+    # bytes for iteration j of a restart cycle; SVD LAPACK-equivalent flops / peak_f64; environment update max(F / 2 /
+    # peak_f64, B / 2 / peak_hbm).  All counts come from the run's own per-bond statistics.
+    PEAK_F, PEAK_B = PEAK_F64_MFMA_TFLOPS * 1e12, 8.0e12
+    kd = eng.krylovdim
+    b_apply = b_lan = b_svd = b_env = 0.0
+    for s_ in stats:
+        one = max(s_.apply_flops / world / PEAK_F, s_.apply_bytes / PEAK_B)
+        b_apply += s_.n_matvec * one
+        b_lan += sum(16.0 * s_.theta_size * (2 * (j % kd) + 4) for j in range(s_.n_matvec)) / PEAK_B
+        b_svd += s_.svd_flops / PEAK_F
+        b_env += max(0.5 * s_.apply_flops / PEAK_F, 0.5 * s_.apply_bytes / PEAK_B)
+    bound = (b_apply + b_lan + b_svd + b_env) / args.steps
+    out["roofline"]["sweep"] = {"frac": bound / sweep_s if sweep_s > 0 else None, "bound_s": bound,
+                                "stage_bound_s": {"apply": b_apply / args.steps, "lanczos_vectors": b_lan / args.steps,
+                                                  "svd": b_svd / args.steps, "env": b_env / args.steps},
+                                "definition": "SURVEY 8(d): sum of per-stage roofline bounds (78.6 TFLOP/s f64, 8.0 TB/s HBM) / sweep time"}
+    # HBM traffic per launch comes from OFFLINE rocprofv3 PMC passes (counters cannot be read live); the number is a committed
+    # constant, not a measurement of this run: see profiles/pmc_traffic.json for how it was collected and corrected
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"L{L}_chi{args.chi}")
         if pmc and world == 1 and args.model == "one_band":
             out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "offline PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes), profiles/pmc_traffic.json: " \
+                                                + str(pmc.get("source", "see file"))
             out["roofline"]["algorithmic_bytes_per_launch"] = sum(s.n_matvec * s.apply_bytes for s in stats) / max(k_n, 1)
     except Exception:
         pass

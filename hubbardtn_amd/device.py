@@ -68,17 +68,25 @@ class HipOps:
 
     def set_exchange(self, rank: int, world: int, fn):
         """caller-supplied reduction: fn(y_ptr, n) must enqueue/perform the sum of y (n complex128 at device pointer
-        y_ptr) over the ranks.  Exceptions abort the solve (the C side sees a non-zero return) and are re-raised by
-        the next engine call through `check_exchange`."""
+        y_ptr) over the ranks.  An exception inside fn cannot cross the C frame: it is stored, the C side sees a non-zero
+        return and aborts the solve, and the engine call that was running re-raises the ORIGINAL exception (with its
+        traceback) through `check_exchange` as soon as the library call has returned -- KeyboardInterrupt / SystemExit
+        included, so a rank that must die does not carry on towards the next collective."""
         def _cb(y_ptr, n, user):
             try:
                 fn(y_ptr, n)
                 return 0
-            except BaseException as e:      # noqa: BLE001 -- must not propagate through the C frame
+            except BaseException as e:      # noqa: BLE001 -- stored and re-raised by check_exchange after the C call
                 self._exc = e
                 return 1
         self._cb = abi.EXCHANGE_FN(_cb) if fn is not None else abi.EXCHANGE_FN()
         abi.check(self.lib, self.lib.htn_ctx_set_exchange(self.ctx, rank, world, self._cb, None), "htn_ctx_set_exchange")
+
+    def check_exchange(self):
+        """re-raise (once) what the exchange hook raised during the library call that has just returned"""
+        e, self._exc = self._exc, None
+        if e is not None:
+            raise e
 
     # ---- memory -----------------------------------------------------------------------------
     def empty_z(self, n):

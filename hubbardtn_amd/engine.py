@@ -172,6 +172,15 @@ class DMRG2:
         if h:
             self.lib.htn_mps_destroy(h)
 
+    def _check(self, rc, what):
+        """status of a library call that may have run the context's exchange hook: an exception raised inside the hook
+        (stored by the context provider, the C side only saw "failed") is re-raised here in preference to the generic
+        library error"""
+        chk = getattr(self.ops, "check_exchange", None)
+        if chk is not None:
+            chk()
+        abi.check(self.lib, rc, what)
+
     # ---- options ----------------------------------------------------------------------------------
     def _opts(self, cutoff=None):
         o = abi.SweepOpts()
@@ -295,7 +304,7 @@ class DMRG2:
         n = self.lib.htn_mps_theta_size(self.handle, i)
         assert x.shape == (n,)
         y = np.zeros(n, dtype=np.complex128)
-        abi.check(self.lib, self.lib.htn_heff2_apply(self.handle, i, x.ctypes.data, y.ctypes.data), "htn_heff2_apply")
+        self._check(self.lib.htn_heff2_apply(self.handle, i, x.ctypes.data, y.ctypes.data), "htn_heff2_apply")
         return y
 
     def plan_apply_dump(self, i, stage):
@@ -330,8 +339,8 @@ class DMRG2:
         self.__dict__.pop("_bond_cache", None)
         st = np.zeros(1, dtype=abi.BOND_STATS_DT)
         o = self._opts(cutoff)
-        abi.check(self.lib, self.lib.htn_bond_update(self.handle, i, direction, 0 if placement == "right" else 1,
-                                                     1 if optimise else 0, C.byref(o), st.ctypes.data), "htn_bond_update")
+        self._check(self.lib.htn_bond_update(self.handle, i, direction, 0 if placement == "right" else 1,
+                                             1 if optimise else 0, C.byref(o), st.ctypes.data), "htn_bond_update")
         s = _stats(st[0])
         if record:
             self.stats.append(s)
@@ -345,7 +354,7 @@ class DMRG2:
         st = np.zeros(n, dtype=abi.BOND_STATS_DT)
         E = C.c_double(0.0)
         o = self._opts()
-        abi.check(self.lib, self.lib.htn_dmrg2_sweep(self.handle, C.byref(o), st.ctypes.data, C.byref(E)), "htn_dmrg2_sweep")
+        self._check(self.lib.htn_dmrg2_sweep(self.handle, C.byref(o), st.ctypes.data, C.byref(E)), "htn_dmrg2_sweep")
         self.stats.extend(_stats(r) for r in st)
         self.energy = E.value
         return self.energy

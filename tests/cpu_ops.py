@@ -50,6 +50,12 @@ class CpuOps:
         self._cb = abi.EXCHANGE_FN(_cb) if fn is not None else abi.EXCHANGE_FN()
         abi.check(self.lib, self.lib.htn_ctx_set_exchange(self.ctx, rank, world, self._cb, None), "htn_ctx_set_exchange")
 
+    def check_exchange(self):
+        """re-raise (once) what the exchange hook raised during the library call that has just returned"""
+        e, self._exc = getattr(self, "_exc", None), None
+        if e is not None:
+            raise e
+
     def __del__(self):
         h, self.ctx = getattr(self, "ctx", None), None
         if h:

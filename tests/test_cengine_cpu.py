@@ -331,3 +331,32 @@ def test_whole_sweep_through_the_c_abi_only():
     lib.htn_mps_destroy(psi)
     lib.htn_mpo_destroy(mpo)
     lib.htn_ctx_destroy(ctx)
+
+
+def test_exception_in_the_exchange_hook_is_reraised_by_the_engine_call():
+    """the reduction hook runs inside the library (one call per matvec): what it raises cannot cross the C frame, so the
+    context provider stores it, the solve is aborted, and the engine call re-raises the ORIGINAL exception -- not a generic
+    HtnError -- once the library call has returned; the next call works again"""
+    from cpu_ops import CpuOps
+    L = 6
+    H = models.hamiltonian(models.OB_Sim([1.0], [4.0]), L)
+    bonds, tens = mps.random_mps(L, (L, 0), 4, seed=2)
+    ops = CpuOps()
+    calls = {"n": 0, "fail": True}
+
+    class Boom(RuntimeError):
+        pass
+
+    def hook(y):
+        calls["n"] += 1
+        if calls["fail"] and calls["n"] == 3:
+            raise Boom("reduction failed on purpose")
+    ops.set_exchange(0, 1, hook)
+    eng = engine.DMRG2(ops, H, bonds, tens, chi_full=32)
+    with pytest.raises(Boom, match="on purpose"):
+        eng.sweep()
+    calls["fail"] = False
+    bonds, tens = mps.random_mps(L, (L, 0), 4, seed=2)
+    eng = engine.DMRG2(ops, H, bonds, tens, chi_full=32)
+    E = eng.sweep()
+    assert np.isfinite(E) and calls["n"] > 3

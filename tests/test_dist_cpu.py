@@ -105,3 +105,26 @@ def test_cxx_engine_sharded_apply_two_ranks_gloo(tmp_path, world):
         assert abs(a - b) <= 1e-10 * abs(b)
     for c, v in gold["spectra_last_sweep"]["4"].items():
         assert max(abs(x - y) for x, y in zip(S0[c], v)) < 1e-9
+
+
+def test_bench_launch_path_with_two_ranks_on_the_cpu_backend():
+    """`bench.py --gpus 2` outside torchrun starts its own two ranks (python -m torch.distributed.run) and relays rank 0's JSON
+    line: the launch path the driver would use on a multi-GPU node, rehearsed on the CPU baseline library over gloo with a tiny
+    chain.  The line must say n_gpus = 2, carry the sweep-level roofline and come from exactly one rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--backend", "cpu", "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--L", "8", "--chi", "32", "--grow", "16x1", "--master-port", "29617"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["config"]["backend"] == "cpu"
+    assert rec["config"]["parallelism"].endswith("x2") and rec["scaling"] == "strong"
+    assert rec["roofline"]["sweep"]["bound_s"] > 0 and abs(rec["energy_per_site"]) < 10.0
