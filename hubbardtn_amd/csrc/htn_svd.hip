@@ -418,6 +418,19 @@ __device__ __forceinline__ void lds_barrier() {
 // Between panels this is block MODIFIED Gram-Schmidt (every panel sees the updated trailing matrix), whose
 // R factor is backward stable like that of column MGS.  R entries are stored by PHYSICAL column index
 // (X[j][phys k] = conj(r_jk)), so nothing is ever swapped and the row permutation handed on is the identity.
+#ifdef HTN_QR_PROF          // diagnostic build only (tools/ring_prof.py --qr): 100 MHz ticks per phase of k_qr_large, block 0
+__device__ long long g_qr_prof[8];
+extern "C" int htn_qr_prof_dump(long long* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qr_prof), sizeof(long long) * 8));
+    return 0;
+}
+#define QR_T(var) const long long var = wall_clock64()
+#define QR_ACC(slot, a, b) qprof[slot] += (b) - (a)
+#else
+#define QR_T(var)
+#define QR_ACC(slot, a, b)
+#endif
 template <int EL>
 __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, int n0, int r,
                                             double2* __restrict__ Xg, int mp, int* s_col, double* s_cn2,
@@ -453,7 +466,12 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
     const double zero2 = s_piv[1];
     bool stop = false;
     int j0 = 0, rank = 0;
+#ifdef HTN_QR_PROF
+    long long qprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // window | panel load | panel steps | flush | trailing | total | panels
+    const long long qt0 = wall_clock64();
+#endif
     while (j0 < r && !stop) {
+        QR_T(q0);
         const int nbmax = r - j0 < 16 ? r - j0 : 16;
         // ---- (a) window: the nbmax largest remaining columns move to logical positions j0 .. ----
         if (wave == 0) {
@@ -490,6 +508,8 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
             if (lane == 0) s_nb = nb;
         }
         __syncthreads();
+        QR_T(q1);
+        QR_ACC(0, q0, q1);
         int nb = s_nb;
         if (nb == 0) break;                          // numerically rank deficient: remaining R rows are zero
         if (nb < nbmax) stop = true;
@@ -512,6 +532,8 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
         if (lane == 0) s_pc[wave] = pc;
         bool pending = owner;
         int nb_eff = nb;
+        QR_T(q2);
+        QR_ACC(1, q1, q2);
         for (int t = 0; t < nb; ++t) {
             if (lane == 0) s_pn[wave] = pending ? cn : -1.0;
             lds_barrier();
@@ -603,6 +625,8 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
             }
         }
         __syncthreads();
+        QR_T(q3);
+        QR_ACC(2, q2, q3);
         if (nb_eff < nb) {                            // zero the positions the early exit left unwritten
             for (int tt = nb_eff + wave; tt < nb; tt += JAC_THREADS / 64)
                 for (int i = lane; i < m0p; i += 64) Qn[tt * ldq + i] = make_double2(0.0, 0.0);
@@ -611,6 +635,8 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
         if (tid < 256 && (tid >> 4) < nb_eff && (tid & 15) < nb)      // rows of R before a column's own pivot step: 0
             Xg[(int64_t)(j0 + (tid >> 4)) * mp + s_pc[tid & 15]] = s_r[tid >> 4][tid & 15];
         __syncthreads();
+        QR_T(q4);
+        QR_ACC(3, q3, q4);
         // ---- (c) trailing update: wave per chunk of 16 logical columns ----
         const int k_first = j0 + nb;
         const int nchunks = (n0 - k_first + 15) >> 4;
@@ -684,10 +710,21 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
             if (valid && l4 == 0) s_cn2[k] = nrm;
         }
         __syncthreads();
+        QR_T(q5);
+        QR_ACC(4, q4, q5);
+#ifdef HTN_QR_PROF
+        qprof[6] += 1;
+#endif
         j0 += nb;
         rank += nb_eff;
     }
     __syncthreads();
+#ifdef HTN_QR_PROF
+    if (tid == 0 && blockIdx.x == 0) {
+        qprof[5] = wall_clock64() - qt0;
+        for (int q = 0; q < 8; ++q) g_qr_prof[q] = qprof[q];
+    }
+#endif
     for (int i = tid; i < n0; i += JAC_THREADS) s_col[i] = i;      // rows of X are physical columns already
     __syncthreads();
     return rank;

@@ -360,3 +360,91 @@ def test_exception_in_the_exchange_hook_is_reraised_by_the_engine_call():
     eng = engine.DMRG2(ops, H, bonds, tens, chi_full=32)
     E = eng.sweep()
     assert np.isfinite(E) and calls["n"] > 3
+
+
+def test_mps_import_export_tables_shuffled_order_and_padded_leading_dimensions():
+    """Python twin of the Julia side's export_mps / import_mps (integration/HubbardHIP.jl): `htn_mps_create` must accept the
+    sub-block table in ANY order, with leading dimensions larger than the block height and gaps between the blocks of the
+    flat vector (TensorKit's fusion-tree views are strided windows of one data vector), plus sub-blocks between sectors the
+    bond tables do not hold (skipped), and `htn_mps_get_site` must hand every block back bit for bit -- the state is then
+    exactly the one the tidy tables describe: same energies from the same sweeps."""
+    lib = CpuOps().lib
+    L = 8
+    Hm = models.hamiltonian(models.OB_Sim([1.0], [4.0]), L)
+    bonds, tens = mps.random_mps(L, (L, 0), 5, seed=77)
+    ops = CpuOps()
+    cm = engine.CMpo(ops, Hm)
+    rng = np.random.default_rng(5)
+
+    def tables(shuffle):
+        bond_ptr, secs, sub_ptr, subs, data_ptr, chunks = [0], [], [0], [], [0], []
+        for b in bonds:
+            secs += [(N, j, n) for (N, j), n in sorted(b.items())]
+            bond_ptr.append(len(secs))
+        for i in range(L):
+            items = list(tens[i].items())
+            if shuffle:
+                items = [items[k] for k in rng.permutation(len(items))]
+                # a sub-block whose right sector is not in the bond table: the import must skip it
+                items.insert(len(items) // 2, (((0, 0), 0, (99, 0)), np.full((2, 2), 7.0 + 0j)))
+            off, flat = 0, []
+            for (l, s, r), blk in items:
+                m, n = blk.shape
+                ld = m + (int(rng.integers(1, 4)) if shuffle else 0)          # padded leading dimension
+                gap = int(rng.integers(0, 5)) if shuffle else 0               # unused elements in front of the block
+                buf = np.full(gap + ld * n, np.nan + 0j)                      # padding is NaN: it must never be read
+                for c in range(n):
+                    buf[gap + c * ld:gap + c * ld + m] = blk[:, c]
+                subs.append((l[0], l[1], s, r[0], r[1], ld, off + gap))
+                flat.append(buf)
+                off += buf.size
+            chunks.append(np.concatenate(flat))
+            sub_ptr.append(len(subs))
+            data_ptr.append(data_ptr[-1] + off)
+        sb = np.zeros(len(subs), dtype=abi.SUBBLOCK_DT)
+        for q, r_ in enumerate(subs):
+            sb[q] = r_
+        return (np.array(bond_ptr, dtype=np.int32), np.array(secs, dtype=np.int32), np.array(sub_ptr, dtype=np.int32), sb,
+                np.array(data_ptr, dtype=np.int64), np.concatenate(chunks))
+
+    def create(t):
+        bp, sec, sp, sb, dp, data = t
+        h = C.c_void_p()
+        assert lib.htn_mps_create(ops.ctx, cm.handle, L, bp.ctypes.data, sec.ctypes.data, sp.ctypes.data, sb.ctypes.data, dp.ctypes.data,
+                                  data.ctypes.data, None, None, C.byref(h)) == 0, lib.htn_last_error()
+        return h
+
+    def export(h):
+        out = []
+        for i in range(L):
+            nb = lib.htn_mps_get_site(h, i, None, None)
+            size = lib.htn_mps_site_size(h, i, None)
+            subs = np.zeros(nb, dtype=abi.SUBBLOCK_DT)
+            flat = np.zeros(max(size, 1), dtype=np.complex128)
+            assert lib.htn_mps_get_site(h, i, subs.ctypes.data, flat.ctypes.data) == nb
+            site = {}
+            for sb in subs:
+                l, r = (int(sb["lN"]), int(sb["lj"])), (int(sb["rN"]), int(sb["rj"]))
+                m, n = bonds[i][l], bonds[i + 1][r]
+                idx = int(sb["off"]) + np.arange(m)[:, None] + int(sb["ld"]) * np.arange(n)[None, :]
+                site[(l, int(sb["s"]), r)] = flat[idx]
+            out.append(site)
+        return out
+
+    h_tidy, h_mess = create(tables(False)), create(tables(True))
+    for i, (a, b) in enumerate(zip(export(h_tidy), export(h_mess))):
+        assert a.keys() == b.keys() and set(a) >= set(tens[i])
+        for key in a:
+            assert np.array_equal(a[key], b[key]), (i, key)
+            if key in tens[i]:
+                assert np.array_equal(a[key], np.asarray(tens[i][key], dtype=np.complex128)), (i, key)     # bit for bit
+            else:
+                assert not a[key].any()                                   # structurally allowed block the caller did not send
+    o = abi.SweepOpts()
+    o.chi_full, o.krylovdim, o.maxrestart, o.lanczos_tol = 48, 30, 3, 1e-12
+    for _ in range(2):
+        E1, E2 = C.c_double(), C.c_double()
+        assert lib.htn_dmrg2_sweep(h_tidy, C.byref(o), None, C.byref(E1)) == 0 and lib.htn_dmrg2_sweep(h_mess, C.byref(o), None, C.byref(E2)) == 0
+        assert E1.value == E2.value and np.isfinite(E1.value)
+    lib.htn_mps_destroy(h_tidy)
+    lib.htn_mps_destroy(h_mess)

@@ -23,6 +23,11 @@ for a in sys.argv[1:]:
     for _ in range(2):
         G.copy_(ops.to_device(M.T.reshape(-1).copy()))
         ops.jacobi_svd(G, V, S, ops.to_device(desc), 1, max(m0, n0), 40, 1e-14, info, desc_host=desc)
+    if hasattr(ops.lib, "htn_qr_prof_dump"):
+        q = np.zeros(8, dtype=np.int64)
+        ops.lib.htn_qr_prof_dump(C.c_void_p(q.ctypes.data))
+        print(f"{a}: k_qr_large us: window {q[0] / 100:.1f}  panel load {q[1] / 100:.1f}  panel steps {q[2] / 100:.1f}  flush {q[3] / 100:.1f}  "
+              f"trailing {q[4] / 100:.1f}  total {q[5] / 100:.1f}  panels {q[6]}")
     out = np.zeros(256 * 8, dtype=np.int64)
     ops.lib.htn_ring_prof_dump(C.c_void_p(out.ctypes.data))
     out = out.reshape(256, 8)
