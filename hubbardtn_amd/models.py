@@ -595,7 +595,17 @@ def hamiltonian(sim: Simulation, L: int):
     sym = symmetry_of(sim)
     if isinstance(sim, OB_Sim):
         if sim.period != 0:
-            raise NotImplementedError("helix (period != 0) is outside the hot-path scope (SURVEY 8f)")
+            # helix / cylinder of circumference `period` (src:464-469): -t (cdc + h.c.){i, i+1} - t (cdc + h.c.){i, i+period},
+            # nearest-neighbour parameters only -- the reference refuses anything else with this very message
+            if len(sim.t) != 1 or len(sim.u) != 1:
+                raise ValueError("Extended models in 2D not implemented.")
+            onsite = {s: [("docc", sim.u[0]), ("n", -sim.mu)] for s in range(L)}
+            pairs = [(i, i + 1, "hop", -sim.t[0]) for i in range(L - 1)]
+            if sim.period > 1:
+                pairs += [(i, i + sim.period, "hop", -sim.t[0]) for i in range(L - sim.period)]
+            else:                                        # period 1: the two terms coincide, -2 t on every bond
+                pairs = [(i, i + 1, "hop", -2.0 * sim.t[0]) for i in range(L - 1)]
+            return _build_mpo(L, onsite, pairs, sym)
         onsite = {s: [("docc", sim.u[0]), ("n", -sim.mu)] for s in range(L)}          # src:424
         J_inter, Ms = (float(x) for x in sim.kwargs.get("JMs", (0.0, 0.0)))
         if Ms != 0.0 and sym is U1U1:                                                 # staggered field, src:459-463

@@ -526,3 +526,18 @@ def test_mpo_compression_keeps_the_operator_and_narrows_the_bond():
         for (wl, wr, op, c) in W.entries:
             k, dN, _ = H.sym.site_ops[op]
             assert W.right[wr][0] == W.left[wl][0] + dN and abs(W.left[wl][1] - k) <= W.right[wr][1] <= W.left[wl][1] + k
+
+
+@pytest.mark.parametrize("period,L", [(3, 5), (4, 5), (2, 4)])
+def test_helix_model_equals_the_dense_hamiltonian_with_two_hopping_ranges(period, L):
+    """`period != 0` (src:464-466): -t (cdc + h.c.) on {i, i+1} AND on {i, i+period} -- a chain wound into a helix / cylinder of
+    that circumference.  On the open chain this is the dense Hamiltonian with hopping t at range 1 and at range `period`;
+    anything but nearest-neighbour parameters is refused with the reference's message (src:468)."""
+    t, U, mu = 0.8, 3.0, 0.2
+    H = models.hamiltonian(models.OB_Sim([t], [U], mu, 1, 1, 2.0, 50, period), L)
+    tvec = [0.0] * period
+    tvec[0] += t
+    tvec[period - 1] += t
+    assert np.abs(ompo.mpo_to_dense(_as_dict(H)) - ed.dense_hamiltonian(L, tvec, [U], mu)).max() < 1e-13
+    with pytest.raises(ValueError, match="Extended models in 2D not implemented."):
+        models.hamiltonian(models.OB_Sim([1.0, 0.1], [4.0], 0.0, 1, 1, 2.0, 50, period), L)
