@@ -66,6 +66,36 @@ static inline bool htn_debug_event_waits() {
     return on;
 }
 
+// ---- Lanczos step record (htn_krylov.hip), published either by k_scale_by_norm / k_publish_record or by workgroup 0 of the
+// NEXT step's first grouped-GEMM launch (htn_gemm.hip) ------------------------------------------------------------------------
+// One 32-byte slot per Lanczos step in host-mapped COHERENT pinned memory, written by ONE lane as two 16-byte stores.  It
+// validates itself: word 3 = serial ^ mix(words 0..2), where `serial` is a number the host chose for exactly this step and
+// never reuses.  The host accepts a slot only when the check reproduces the serial it expects, so neither a slot left over
+// from an earlier solve, nor a half-arrived record, nor any reordering of the two stores on their way to host memory can be
+// taken for the step's result; and the CPU never writes into this block (no sentinel), so no CPU store can share a cache line
+// with a device store.
+struct LanRecord {
+    unsigned long long w[4];      // bits of <v_j,w> pass 1 (re), pass 2 (re), |w|^2 after orthogonalisation, check
+};
+__host__ __device__ __forceinline__ unsigned long long lan_rotl(unsigned long long x, int r) { return (x << r) | (x >> (64 - r)); }
+__host__ __device__ __forceinline__ unsigned long long lan_check(unsigned long long w0, unsigned long long w1, unsigned long long w2,
+                                                                 unsigned long long serial) {
+    return serial ^ lan_rotl(w0, 13) ^ lan_rotl(w1, 29) ^ lan_rotl(w2, 47) ^ 0x9E3779B97F4A7C15ull;
+}
+#define HTN_DOT_BLOCKS 256        // partial sums per Krylov vector / per norm (htn_krylov.hip: DOT_BLOCKS)
+// optional side job of a grouped-GEMM launch: workgroup 0 reduces the HTN_DOT_BLOCKS partial sums of |w|^2 the previous
+// Lanczos step left behind and publishes that step's record {c1[0].re, c2[0].re, |w|^2} -- which saves the step a kernel of
+// its own (the normalisation itself is folded into the next step's Gram-Schmidt pass).  rec_out == nullptr: nothing to do.
+struct HtnGemmPublish {
+    const double* norm_partial;
+    const double2* c1;
+    const double2* c2;
+    LanRecord* rec_out;
+    unsigned long long serial;
+};
+int htn_grouped_gemm_launch(const void* const* bufs_host, const htn_tile* tiles, int32_t n_tiles, const htn_seg* segs,
+                            const HtnGemmPublish* pub, hipStream_t stream);
+
 // per-stream scratch of the multi-launch drivers (htn_krylov.hip, htn_svd.hip): owned by the stream's registry entry,
 // released by the backend that owns the stream (HipBackend::~HipBackend) -- nothing thread-local, nothing shared between
 // two contexts.  A caller of the kernel-level ABI that brings its own stream keeps its entry until the process ends.

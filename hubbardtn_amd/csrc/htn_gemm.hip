@@ -172,7 +172,7 @@ extern "C" int htn_gemm_prof_dump(long long* out, int n) {
 #define GEMM_MINOCC 6     // workgroups (one wave per SIMD each) co-resident per CU
 #endif
 __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_MINOCC) void k_grouped_gemm_z(BufTable bufs, const htn_tile* __restrict__ tiles,
-                                                                       const htn_seg* __restrict__ segs) {
+                                                                       const htn_seg* __restrict__ segs, HtnGemmPublish pub) {
     __shared__ double red[3 * 64 * 8];      // partial accumulators of the K groups 1..3 (12 KiB); also the split-K flag
     __shared__ htn_seg s_desc[GEMM_DESC_MAX];
 
@@ -182,6 +182,21 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_MINOCC) void k_grouped_gemm_z
 #endif
     const htn_tile T = tiles[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    if (pub.rec_out && blockIdx.x == 0 && tid < 64) {       // (wave-uniform) the Lanczos driver's record of the previous step
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < HTN_DOT_BLOCKS / 64; ++b) t += pub.norm_partial[tid + 64 * b];      // same order as k_scale_by_norm
+        t = wave_sum(t);
+        if (tid == 0) {
+            const unsigned long long w0 = (unsigned long long)__double_as_longlong(pub.c1[0].x);
+            const unsigned long long w1 = (unsigned long long)__double_as_longlong(pub.c2[0].x);
+            const unsigned long long w2 = (unsigned long long)__double_as_longlong(t);
+            ulonglong2* out = (ulonglong2*)pub.rec_out;
+            out[0] = make_ulonglong2(w0, w1);
+            out[1] = make_ulonglong2(w2, lan_check(w0, w1, w2, pub.serial));
+            __threadfence_system();
+        }
+    }
     // (readfirstlane: the wave index, hence the K group, the cursor and every segment descriptor field, lives in SGPRs)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // quadrants the tile has, K groups the waves form: wave = grp * nquad + quad
@@ -354,12 +369,19 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_MINOCC) void k_grouped_gemm_z
 #endif
 }
 
-extern "C" int htn_grouped_gemm_z(const void* const* bufs_host, const htn_tile* tiles, int32_t n_tiles,
-                                  const htn_seg* segs, void* stream) {
-    if (n_tiles <= 0) return 0;
+int htn_grouped_gemm_launch(const void* const* bufs_host, const htn_tile* tiles, int32_t n_tiles, const htn_seg* segs,
+                            const HtnGemmPublish* pub, hipStream_t stream) {
+    if (n_tiles <= 0) return pub && pub->rec_out ? fail_msg("htn_grouped_gemm_launch: a record to publish but no tiles") : 0;
     BufTable bt;
     for (int i = 0; i < HTN_MAX_BUFS; ++i) bt.p[i] = (double2*)bufs_host[i];
-    hipLaunchKernelGGL(k_grouped_gemm_z, dim3(n_tiles), dim3(64 * GEMM_WAVES), 0, (hipStream_t)stream, bt, tiles, segs);
+    HtnGemmPublish p = {nullptr, nullptr, nullptr, nullptr, 0ull};
+    if (pub) p = *pub;
+    hipLaunchKernelGGL(k_grouped_gemm_z, dim3(n_tiles), dim3(64 * GEMM_WAVES), 0, stream, bt, tiles, segs, p);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" int htn_grouped_gemm_z(const void* const* bufs_host, const htn_tile* tiles, int32_t n_tiles,
+                                  const htn_seg* segs, void* stream) {
+    return htn_grouped_gemm_launch(bufs_host, tiles, n_tiles, segs, nullptr, (hipStream_t)stream);
 }

@@ -17,7 +17,7 @@
 
 #include "htn_common.h"
 
-#define DOT_BLOCKS 256        // partial sums per vector = slices of the vector (4 per lane of the reducing wave)
+#define DOT_BLOCKS HTN_DOT_BLOCKS   // partial sums per vector = slices of the vector (4 per lane of the reducing wave)
 #define DOT_THREADS 256       // threads of the axpy / scale kernels
 #define DOT_CHUNK 32          // vectors handled per pass over the slice of w (krylovdim + 1 <= 31 by default)
 
@@ -147,17 +147,41 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__
 // basis values of the element are still in registers, partial_out[i][b] = sum over slice b of conj(V_i) * w_new.
 // One read of the Krylov basis instead of two (the basis is the traffic of a Lanczos step: (j+1) x |theta|).
 // 256 threads = one wave per SIMD, so the CH basis values + 2 CH accumulators per thread fit the register file.
+// DEFERRED NORMALISATION (norm_prev != nullptr): the newest basis row V[nvec-1] is still the raw, unnormalised vector the
+// previous step's second update left behind (|raw|^2 = sum norm_prev = beta^2), and w = H raw = beta H v.  This kernel reads
+// that row anyway, so it does the previous step's normalisation on the way: s = 1 / beta, the row is written back as
+// v = s raw, w is taken as s w, and the dots of K2 (taken with the raw row and the raw w) become c_i = s P_i (i < nvec-1),
+// c_last = s^2 P_last.  The separate scale kernel of every step is gone; its record is published by the next matvec launch.
 template <int CH>
-__global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__ w, const double2* __restrict__ V,
+__global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__ w, double2* __restrict__ V,
                                                            int64_t ldv, int nvec,
                                                            const double2* __restrict__ partial_in,
                                                            double2* __restrict__ c_out, int c_index, double sign,
-                                                           int64_t n, double2* __restrict__ partial_out) {
+                                                           int64_t n, double2* __restrict__ partial_out,
+                                                           const double* __restrict__ norm_prev) {
     __shared__ double cs[64][2];
     __shared__ double red[DOT_THREADS / 64][CH][2];
+    __shared__ double s_scale;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int last = nvec - 1;
+    if (tid < 64) {                                   // (wave 0) scale of the deferred normalisation, same order as every norm sum
+        double t = 1.0;
+        if (norm_prev) {
+            t = 0.0;
+#pragma unroll
+            for (int b = 0; b < DOT_BLOCKS / 64; ++b) t += norm_prev[tid + 64 * b];
+            t = wave_sum(t);
+            t = t > 0.0 ? 1.0 / sqrt(t) : 0.0;
+        }
+        if (tid == 0) s_scale = t;
+    }
+    __syncthreads();
+    const double s = s_scale;
     for (int i = wave; i < nvec; i += DOT_THREADS / 64) {
-        const double2 r = reduce_partials(partial_in + (int64_t)i * DOT_BLOCKS, lane);
+        double2 r = reduce_partials(partial_in + (int64_t)i * DOT_BLOCKS, lane);
+        const double f = (norm_prev && i == last) ? s * s : s;
+        r.x *= f;
+        r.y *= f;
         if (lane == 0) {
             cs[i][0] = r.x;
             cs[i][1] = r.y;
@@ -166,6 +190,7 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
     }
     if (tid >= nvec && tid < 64) cs[tid][0] = cs[tid][1] = 0.0;
     __syncthreads();
+    const bool fix = norm_prev != nullptr;
     const int64_t per = (n + DOT_BLOCKS - 1) / DOT_BLOCKS;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
@@ -179,6 +204,18 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
             const int i = c < nvec ? c : nvec - 1;
             v[c] = V[(int64_t)i * ldv + j];
         }
+        if (fix) {                                    // (uniform) normalise the newest row on the way and write it back
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (c >= last) {                      // c == last, and the clamped copies beyond it (their coefficients are 0)
+                    v[c].x *= s;
+                    v[c].y *= s;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (c == last) V[(int64_t)last * ldv + j] = v[c];
+        }
         double sr = 0.0, si = 0.0;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {                // cs[c] = 0 beyond nvec
@@ -186,8 +223,8 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
             si += cs[c][0] * v[c].y + cs[c][1] * v[c].x;
         }
         double2 x = w[j];
-        x.x += sign * sr;
-        x.y += sign * si;
+        x.x = fma(x.x, s, sign * sr);
+        x.y = fma(x.y, s, sign * si);
         w[j] = x;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -216,31 +253,16 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
     }
 }
 
-static void launch_axpy_dots(double2* w, const double2* V, int64_t ldv, int nvec, const double2* partial_in, double2* c_out,
-                             int c_index, double sign, int64_t n, double2* partial_out, hipStream_t st) {
+static void launch_axpy_dots(double2* w, double2* V, int64_t ldv, int nvec, const double2* partial_in, double2* c_out,
+                             int c_index, double sign, int64_t n, double2* partial_out, const double* norm_prev, hipStream_t st) {
 #define HTN_AD(CHV)                                                                                              \
     hipLaunchKernelGGL(k_axpy_dots<CHV>, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, ldv, nvec, partial_in, c_out, \
-                       c_index, sign, n, partial_out)
+                       c_index, sign, n, partial_out, norm_prev)
     if (nvec <= 4) HTN_AD(4);
     else if (nvec <= 8) HTN_AD(8);
     else if (nvec <= 16) HTN_AD(16);
     else HTN_AD(32);
 #undef HTN_AD
-}
-
-// Step record handed to the host, one 32-byte slot per Lanczos step in host-mapped COHERENT pinned memory.  It is written
-// by ONE lane of the step's LAST kernel as two 16-byte stores and validates itself: word 3 = serial ^ mix(words 0..2),
-// where `serial` is a number the host chose for exactly this step and never reuses.  The host accepts a slot only when
-// the check reproduces the serial it expects, so neither a slot left over from an earlier solve, nor a half-arrived
-// record, nor any reordering of the two stores on their way to host memory can be taken for the step's result; and
-// the CPU never writes into this block (no sentinel), so no CPU store can share a cache line with a device store.
-struct LanRecord {
-    unsigned long long w[4];      // bits of <v_j,w> pass 1 (re), pass 2 (re), |w|^2 after orthogonalisation, check
-};
-__host__ __device__ __forceinline__ unsigned long long lan_rotl(unsigned long long x, int r) { return (x << r) | (x >> (64 - r)); }
-__host__ __device__ __forceinline__ unsigned long long lan_check(unsigned long long w0, unsigned long long w1, unsigned long long w2,
-                                                                 unsigned long long serial) {
-    return serial ^ lan_rotl(w0, 13) ^ lan_rotl(w1, 29) ^ lan_rotl(w2, 47) ^ 0x9E3779B97F4A7C15ull;
 }
 
 // dst = src / sqrt(sum norm_partial); with rec_out, block 0 publishes the step record {c1[0].re, c2[0].re, |w|^2}
@@ -275,6 +297,26 @@ __global__ __launch_bounds__(DOT_THREADS) void k_scale_by_norm(double2* __restri
     for (int64_t j = (int64_t)blockIdx.x * DOT_THREADS + tid; j < n; j += (int64_t)gridDim.x * DOT_THREADS) {
         const double2 v = src[j];
         dst[j] = make_double2(v.x * s, v.y * s);
+    }
+}
+
+// the record of a step that no further matvec launch follows (the last step of a restart cycle): one wave
+__global__ __launch_bounds__(64) void k_publish_record(const double* __restrict__ norm_partial, const double2* __restrict__ c1,
+                                                       const double2* __restrict__ c2, LanRecord* __restrict__ rec_out,
+                                                       unsigned long long serial) {
+    const int tid = threadIdx.x;
+    double t = 0.0;
+#pragma unroll
+    for (int b = 0; b < DOT_BLOCKS / 64; ++b) t += norm_partial[tid + 64 * b];
+    t = wave_sum(t);
+    if (tid == 0) {
+        const unsigned long long w0 = (unsigned long long)__double_as_longlong(c1[0].x);
+        const unsigned long long w1 = (unsigned long long)__double_as_longlong(c2[0].x);
+        const unsigned long long w2 = (unsigned long long)__double_as_longlong(t);
+        ulonglong2* out = (ulonglong2*)rec_out;
+        out[0] = make_ulonglong2(w0, w1);
+        out[1] = make_ulonglong2(w2, lan_check(w0, w1, w2, serial));
+        __threadfence_system();
     }
 }
 
@@ -511,21 +553,29 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
 
     bool timed_step[LAN_SLOTS] = {false};
     unsigned long long step_serial[LAN_SLOTS] = {0};
-    auto matvec = [&](double2* x, double2* y) -> int {
+    auto matvec = [&](double2* x, double2* y, const HtnGemmPublish* pub) -> int {
         if (zero_y) HIP_TRY(hipMemsetAsync(y, 0, sizeof(double2) * n, st));
+        bool published = pub == nullptr;
         for (int s = 0; s < n_stages; ++s) {
             const void* bufs[HTN_MAX_BUFS];
             for (int b = 0; b < HTN_MAX_BUFS; ++b) bufs[b] = stages[s].bufs[b];
             bufs[x_slot] = x;
             bufs[y_slot] = y;
-            if (htn_grouped_gemm_z(bufs, stages[s].tiles, stages[s].n_tiles, stages[s].segs, st)) return 1;
+            const bool here = !published && stages[s].n_tiles > 0;        // the first launch of the matvec carries the record
+            if (htn_grouped_gemm_launch(bufs, stages[s].tiles, stages[s].n_tiles, stages[s].segs, here ? pub : nullptr, st)) return 1;
+            published |= here;
         }
+        if (!published)         // (a matvec without a single tile: publish by the one-wave kernel)
+            hipLaunchKernelGGL(k_publish_record, dim3(1), dim3(64), 0, st, pub->norm_partial, pub->c1, pub->c2, pub->rec_out, pub->serial);
         if (exchange && exchange(y, n, user)) return fail_msg("htn_lanczos_z: the exchange hook reported a failure");
         return 0;
     };
-    // one Lanczos step, fully enqueued: w = H v_j; two Gram-Schmidt passes against V[0..j]; v_{j+1} = w/|w|; the last
-    // kernel publishes the step's record under a fresh serial
-    auto enqueue_step = [&](int j) -> int {
+    // One Lanczos step, fully enqueued: w = H V[j]; two Gram-Schmidt passes against V[0..j]; the result stays UNNORMALISED in
+    // V[j+1] with its squared norm in norm_partial.  For j > 0 (inside a cycle) V[j] itself is still the raw vector of step
+    // j - 1: its normalisation is folded into this step's first update (k_axpy_dots, norm_prev) and the record of step j - 1 is
+    // published by this step's first matvec launch -- four kernels per step instead of five.  The last step of a cycle
+    // publishes its own record (nothing follows it).  `first` = V[j] is already normalised (start / Ritz vector).
+    auto enqueue_step = [&](int j, bool first) -> int {
         double2* vj = V + (int64_t)j * n;
         double2* w = V + (int64_t)(j + 1) * n;
         // HIP events around a SAMPLE of the matvec launches (every 8th): an event is a marker packet that costs ~5 us
@@ -534,17 +584,22 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         timed_step[j] = timed;
         ++R->sample;
         step_serial[j] = ++R->serial;
+        HtnGemmPublish pub = {nullptr, nullptr, nullptr, nullptr, 0ull};
+        if (!first) pub = {norm_partial, (const double2*)(c1 + (j - 1)), (const double2*)(c2 + (j - 1)), R->d_rec + (j - 1), step_serial[j - 1]};
         if (timed) HIP_TRY(hipEventRecord(R->ev_mv0[j], st));
-        if (matvec(vj, w)) return 1;
+        if (matvec(vj, w, first ? nullptr : &pub)) return 1;
         if (timed) HIP_TRY(hipEventRecord(R->ev_mv1[j], st));
+        if (!first && event_waits) HIP_TRY(hipEventRecord(R->ev_done[j - 1], st));
         // two-pass classical Gram-Schmidt in three passes over the basis: dots | update + dots (fused) | update + norm
         launch_dots_partial(V, n, j + 1, w, n, partial, st);
-        launch_axpy_dots(w, V, n, j + 1, partial, c1 + j, j, -1.0, n, partial2, st);
+        launch_axpy_dots(w, V, n, j + 1, partial, c1 + j, j, -1.0, n, partial2, first ? (const double*)nullptr : norm_partial, st);
         hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial2, c2 + j, j,
                            -1.0, n, norm_partial);
-        hipLaunchKernelGGL(k_scale_by_norm, dim3(grid_for(n)), dim3(DOT_THREADS), 0, st, w, w, norm_partial, n, R->d_rec + j,
-                           (const double2*)(c1 + j), (const double2*)(c2 + j), step_serial[j]);
-        if (event_waits) HIP_TRY(hipEventRecord(R->ev_done[j], st));
+        if (j == kd - 1) {
+            hipLaunchKernelGGL(k_publish_record, dim3(1), dim3(64), 0, st, (const double*)norm_partial, (const double2*)(c1 + j),
+                               (const double2*)(c2 + j), R->d_rec + j, step_serial[j]);
+            if (event_waits) HIP_TRY(hipEventRecord(R->ev_done[j], st));
+        }
         return 0;
     };
     // read slot j if it holds the record of THIS step (see LanRecord): true = accepted
@@ -592,11 +647,11 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         // Software pipeline of depth 1: step j+1 is enqueued BEFORE the host waits for step j's record, so the
         // GPU never idles during the host's convergence test.  If step j converges, step j+1 was speculative:
         // it only wrote Krylov row j+2, device scalars j+1 and record slot j+1, which nothing reads afterwards.
-        if (enqueue_step(0)) return 1;
+        if (enqueue_step(0, true)) return 1;
         ++nmv;
         for (int j = 0; j < kd; ++j) {
             if (j + 1 < kd) {
-                if (enqueue_step(j + 1)) return 1;
+                if (enqueue_step(j + 1, false)) return 1;
                 ++nmv;
             }
             double a1 = 0.0, a2 = 0.0, nn = 0.0;
