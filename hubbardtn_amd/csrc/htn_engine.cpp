@@ -8,6 +8,8 @@
 // tridiagonal coefficients and the singular values (needed for the global truncation rule, App. A.6).
 // Host C++ (no HIP): device work goes through htn::Backend.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -452,8 +454,11 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
                               info_dev, &so))
         return 1;
     if (jac_used > 0) sweeps_hint[i + 1] = jac_used;
+    static const bool dbg_timers = getenv("HTN_DEBUG_HOST_TIMERS") != nullptr;
+    const double tA = now();
     std::vector<double> s_host(s_elems + (i_elems + 1) / 2);
     if (be->download(s_host.data(), S->p, sizeof(double) * s_elems + sizeof(int32_t) * i_elems)) return 1;
+    const double tB = now();
     const int32_t* info_h = (const int32_t*)(s_host.data() + s_elems);
     int jac_sweeps = 0;
     for (int b = 0; b < (svd_shard ? sc->n_own : nb); ++b) {        // (sharded: the counts of this rank's own blocks)
@@ -464,15 +469,23 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
     std::vector<int> lens(nb), qd(nb);
     std::vector<std::vector<int>> order(nb);
     std::vector<double> vals;
+    vals.reserve((size_t)sp.s_size);
+    std::vector<std::pair<double, int>> tmp;
     for (int b = 0; b < nb; ++b) {
         const int len = sp.desc[b].n;
         const double* sv = s_host.data() + sp.desc[b].s_off;
         lens[b] = len;
         qd[b] = sym.qdim(sp.mids[b]);
+        tmp.resize(len);
+        for (int k = 0; k < len; ++k) tmp[k] = {sv[k], k};
+        std::sort(tmp.begin(), tmp.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& c) {
+            return a.first != c.first ? a.first > c.first : a.second < c.second;
+        });
         order[b].resize(len);
-        for (int k = 0; k < len; ++k) order[b][k] = k;
-        std::stable_sort(order[b].begin(), order[b].end(), [&](int a, int c) { return sv[a] > sv[c]; });
-        for (int k = 0; k < len; ++k) vals.push_back(sv[order[b][k]]);
+        for (int k = 0; k < len; ++k) {
+            order[b][k] = tmp[k].second;
+            vals.push_back(tmp[k].first);
+        }
     }
     std::vector<int> counts;
     double tw = 0.0, nrm = 0.0;
@@ -486,6 +499,7 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
     for (double v : vals) positive += v > 0.0;
     if (kept_tot == 0 || !(nrm > 0.0)) return set_error("htn_bond_update: nothing kept by the truncation on bond %d", i + 1);
     BondP mid = std::make_shared<Bond>(mid_items);
+    const double tC = now();
     // hint for the next visit of this bond: the smallest kept value, valid only if the dimension limit (not the number
     // of available states) ended the kept set
     if (o.chi_full > 0 && tw > 0.0 && kept_tot < positive) {
@@ -524,6 +538,7 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
         return f;
     });
     if (!fc) return 1;
+    const double tD = now();
     idx_host.clear();
     for (int b = 0; b < nb; ++b)
         for (int k = 0; k < counts[b]; ++k) idx_host.push_back(order[b][k]);
@@ -546,6 +561,9 @@ int htn_mps::update_bond(int i, int direction, bool right, bool optimise, const 
     site_buf[i] = DView{out.base, out.off};
     site_lay[i + 1] = fc->layB;
     site_buf[i + 1] = DView{out.base, out.off + sizeA};
+    if (dbg_timers)
+        fprintf(stderr, "bond %d: svd call %.1f us, download %.1f, sort+truncate %.1f, finalize plan %.1f, enqueue %.1f  misses %lld hits %lld nvals %zu\n", i + 1,
+                (tA - t0 - t_plan - t_lan) * 1e6, (tB - tA) * 1e6, (tC - tB) * 1e6, (tD - tC) * 1e6, (now() - tD) * 1e6, (long long)misses, (long long)hits, vals.size());
     if (o.profile) be->sync();
     const double t_svd = now() - t0 - t_plan - t_lan;
     if (right ? left_env(i) : right_env(i + 1)) return 1;

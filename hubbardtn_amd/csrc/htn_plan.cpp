@@ -1043,42 +1043,65 @@ void truncate(const std::vector<double>& vals, const std::vector<int>& lens, con
     const double rel_floor = 1e-14;
     const size_t nsec = lens.size();
     counts.assign(nsec, 0);
-    double smax = 0.0;
-    for (double v : vals) smax = std::max(smax, v);
-    struct It {
+    double smax = 0.0, total = 0.0;
+    for (double v : vals) {
+        smax = std::max(smax, v);
+        total += v * v;
+    }
+    // The candidates of every sector are a PREFIX of its descending list (both filters are monotone inside a sector), so the
+    // global order "key descending, ties by sector then index" is a k-way merge of at most a few dozen sorted runs: a heap
+    // of one cursor per sector instead of a sort of every value (this runs on the host with the GPU idle, once per bond).
+    struct Cur {
         double key;
-        int sid, idx, dim;
-        double val;
+        int sid, idx;
     };
-    std::vector<It> cand;
+    auto worse = [](const Cur& a, const Cur& b) {        // heap order: the BEST cursor on top
+        if (a.key != b.key) return a.key < b.key;
+        if (a.sid != b.sid) return a.sid > b.sid;
+        return a.idx > b.idx;
+    };
+    std::vector<size_t> start(nsec);
+    std::vector<Cur> heap;
     size_t p = 0;
+    for (size_t k = 0; k < nsec; ++k) {
+        start[k] = p;
+        p += (size_t)lens[k];
+    }
+    auto admissible = [&](size_t k, int i) {
+        if (i >= lens[k]) return false;
+        const double v = vals[start[k] + i], schmidt = v / sqrt((double)qdims[k]);
+        return schmidt > cutoff && v > rel_floor * smax;
+    };
+    auto key_of = [&](size_t k, int i) { return weighting == 0 ? vals[start[k] + i] : vals[start[k] + i] / sqrt((double)qdims[k]); };
     for (size_t k = 0; k < nsec; ++k)
-        for (int i = 0; i < lens[k]; ++i, ++p) {
-            const double v = vals[p], schmidt = v / sqrt((double)qdims[k]);
-            if (!(schmidt > cutoff) || !(v > rel_floor * smax)) continue;
-            cand.push_back({weighting == 0 ? v : schmidt, (int)k, i, qdims[k], v});
-        }
-    std::sort(cand.begin(), cand.end(), [](const It& a, const It& b) {
-        if (a.key != b.key) return a.key > b.key;
-        if (a.sid != b.sid) return a.sid < b.sid;
-        return a.idx < b.idx;
-    });
-    size_t keep_n = cand.size();
-    if (chi_full > 0 && keep_n) {
-        int64_t tot = 0;
-        for (size_t i = 0; i < cand.size(); ++i) {
-            tot += cand[i].dim;
-            if (tot > chi_full) {
-                keep_n = std::max<size_t>(i, 1);
+        if (admissible(k, 0)) heap.push_back({key_of(k, 0), (int)k, 0});
+    std::make_heap(heap.begin(), heap.end(), worse);
+    int64_t tot = 0;
+    double kept_w = 0.0;
+    size_t kept = 0;
+    while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), worse);
+        const Cur c = heap.back();
+        heap.pop_back();
+        if (chi_full > 0) {
+            tot += qdims[c.sid];
+            if (tot > chi_full && kept > 0) break;      // (the largest multiplet is always kept)
+            if (tot > chi_full) {                        // the very first candidate alone exceeds the limit: keep it, stop
+                counts[c.sid] += 1;
+                const double v = vals[start[c.sid] + c.idx];
+                kept_w += v * v;
+                ++kept;
                 break;
             }
         }
-    }
-    double total = 0.0, kept_w = 0.0;
-    for (double v : vals) total += v * v;
-    for (size_t i = 0; i < keep_n; ++i) {
-        counts[cand[i].sid] += 1;
-        kept_w += cand[i].val * cand[i].val;
+        counts[c.sid] += 1;
+        const double v = vals[start[c.sid] + c.idx];
+        kept_w += v * v;
+        ++kept;
+        if (admissible((size_t)c.sid, c.idx + 1)) {
+            heap.push_back({key_of((size_t)c.sid, c.idx + 1), c.sid, c.idx + 1});
+            std::push_heap(heap.begin(), heap.end(), worse);
+        }
     }
     trunc_weight = total > 0.0 ? (total - kept_w) / total : 0.0;
     kept_norm = sqrt(kept_w);
