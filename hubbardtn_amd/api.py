@@ -203,6 +203,12 @@ def compute_groundstate(simul: Simulation, L: int | None = None, tol: float = 1e
     psi0 = init_state if init_state is not None else initialize_mps(H, simul.P, simul.bond_dim, spin, simul.Q)
     scheme = truncdim(chi) if chi is not None else truncbelow(10.0 ** (-simul.svalue))
     if isinstance(H, InfiniteHamiltonian):       # src:1010; the VUMPS / GradientGrassmann polish (src:1025-1027) is out of scope
+        if chi is None and _idmrg.reference_cell_sites(simul) == 1:
+            # the reference's branch for length(H) == 1 (src:1012-1022): VUMPS at fixed space, the space grown by VUMPSSvdCut and
+            # cut by SvdCut(truncbelow(10^-svalue)) until it stops changing.  VUMPS-free route: the same self-consistent space is
+            # the fixed point of two-site updates with that Schmidt cut -- IDMRG2 -- once the cut is expressed for the doubled cell
+            # this library uses (idmrg.schmidt_cut_scale: one sector family per bond instead of both at half weight)
+            scheme = truncbelow(_idmrg.schmidt_cut_scale(simul) * 10.0 ** (-simul.svalue))
         alg = IDMRG2(trscheme=scheme, tol=tol, verbosity=verbosity, maxiter=maxiter)
     else:
         alg = DMRG2(trscheme=scheme, tol=tol, verbosity=verbosity, maxiter=maxiter)

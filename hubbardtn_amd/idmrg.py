@@ -43,6 +43,27 @@ def cell_sites(sim) -> int:
     return unit_cell(int(sim.P), int(sim.Q)) * B
 
 
+def reference_cell_sites(sim) -> int:
+    """length(H) of the reference: T B with T = 1 for the chemical-potential models (src:417, 841)"""
+    B = int(sim.bands)
+    if models.symmetry_of(sim).kind == 2:
+        return B
+    return unit_cell(int(sim.P), int(sim.Q)) * B
+
+
+def schmidt_cut_scale(sim) -> float:
+    """factor between a Schmidt-value cut applied to the reference's state and the same cut applied here.
+    Only the one-site unit cell of the chemical-potential one-band model differs (the branch src:1012-1022, VUMPS +
+    SvdCut(truncbelow)): its uniform MPS carries BOTH sector families on every bond -- (even parity, integer spin) and
+    (odd parity, half-integer spin), which one site translation maps onto each other -- as two blocks of equal weight 1/2,
+    so its normalised Schmidt values are the family's values divided by sqrt 2.  The doubled cell used here (cell_sites)
+    keeps ONE family per bond with weight 1: truncbelow(eta) on the reference's state keeps exactly the multiplets
+    truncbelow(sqrt 2 eta) keeps here.  Inferred from the structure of the state, not verifiable without MPSKit; what can be
+    checked is the reference's own constant: test/OBC.jl:20 (-1.03541433, atol 1e-3) is met at 7e-4 with the factor and
+    missed (1.1e-3) without it (tests/test_nou1_cpu.py)."""
+    return float(np.sqrt(2.0)) if cell_sites(sim) == 2 * reference_cell_sites(sim) else 1.0
+
+
 def _spectrum_distance(a: dict, b: dict, dN: int, sym=models.SU2U1) -> float:
     """|| S_a - S_b || over sectors, b's labels shifted back by dN, shorter spectra zero padded"""
     keys = set(a) | {(N - dN, j) for (N, j) in b}

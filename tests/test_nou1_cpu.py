@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from cpu_ops import CpuOps
-from hubbardtn_amd import api, engine, models, mps
+from hubbardtn_amd import idmrg, api, engine, models, mps
 from oracle import ed, mpo as ompo
 
 
@@ -47,22 +47,28 @@ def test_no_u1_sweep_finds_the_grand_canonical_ground_state(cpu_ops, mu):
 
 
 def test_infinite_chain_at_half_filling_matches_the_u1_mode_and_the_reference_constants(cpu_ops):
-    """mu = U/2 is half filling by particle-hole symmetry.  One band, U = 1: E + mu n equals the fixed-filling IDMRG2 value
-    (test/OB.jl: -1.037173) to 2e-4 and sits 1.7e-3 from test/OBC.jl:20's -1.03541433 (atol 1e-3 there: that number
-    comes from the reference's VUMPS + SvdCut loop for one-site unit cells, src:1012-1022, a different algorithm and
-    truncation path -- agreement is asserted at 1e-2).  Two bands, U = 1, mu = 0.5 (test/MBC.jl:22-59): -1.01631556 at
+    """mu = U/2 is half filling by particle-hole symmetry.  One band, U = 1, the reference's one-site unit cell (its VUMPS +
+    SvdCut branch, src:1012-1022): through `compute_groundstate` -- IDMRG2 on the doubled cell with the Schmidt cut
+    expressed for it (idmrg.schmidt_cut_scale) -- E + mu n lands INSIDE the atol 1e-3 of test/OBC.jl:20's -1.03541433
+    (7e-4); with the bare cut it equals the fixed-filling value (test/OB.jl: -1.037173 at the loose settings used there,
+    -1.03647 converged) and misses the constant by 1.1e-3.  Two bands, U = 1, mu = 0.5 (test/MBC.jl:22-59): -1.01631556 at
     the reference's atol 1e-1."""
     sim = api.OBC_Sim2([1.0], [1.0], 0.5, 2.0, 8)
     H = api.hamiltonian(sim)
-    psi = api.initialize_mps(H, sim.bond_dim, ops=cpu_ops)              # the two-argument form of src:961
-    psi, envs, delta = api.find_groundstate(psi, H, api.IDMRG2(trscheme=api.truncbelow(1e-2), tol=2e-3, maxiter=12,
-                                                              eigsolve_tol=1e-9, sweeps_per_step=3))
+    assert idmrg.reference_cell_sites(sim) == 1 and len(H) == 2 and abs(idmrg.schmidt_cut_scale(sim) - np.sqrt(2.0)) < 1e-15
+    res = api.compute_groundstate(sim, tol=1e-4, maxiter=40, init_state=api.initialize_mps(H, sim.bond_dim, ops=cpu_ops))
+    psi = res["groundstate"]
     n = api.density_state(psi)
     E0 = float(np.sum(api.expectation_value(psi, H))) / len(H) + 0.5 * float(n.mean())
     assert np.abs(n - 1.0).max() < 1e-4
-    # (with truncbelow(1e-2) the value depends at the 1e-3 level on which Schmidt values sit next to the threshold: the
-    # predicted windows of the warm-started growth land 7e-4 from the constant, randomly started ones 3e-4)
-    assert abs(E0 - (-1.037173)) < 1e-3 and abs(E0 - (-1.03541433)) < 1e-2
+    assert abs(E0 - (-1.03541433)) < 1e-3, E0                 # test/OBC.jl:20, 30 at its own tolerance
+    # the bare cut (what the two-site-cell models use): the fixed-filling number, outside that tolerance
+    psi2 = api.initialize_mps(H, sim.bond_dim, ops=cpu_ops)
+    psi2, _, _ = api.find_groundstate(psi2, H, api.IDMRG2(trscheme=api.truncbelow(1e-2), tol=1e-4, maxiter=40, eigsolve_tol=1e-10,
+                                                        sweeps_per_step=4))
+    n2 = api.density_state(psi2)
+    E2 = float(np.sum(api.expectation_value(psi2, H))) / len(H) + 0.5 * float(n2.mean())
+    assert abs(E2 - (-1.037173)) < 1e-3 and 1e-3 < abs(E2 - (-1.03541433)) < 1e-2 and E2 < E0
     t = np.array([[0.5, 0.0, 1.0, 0.0], [0.0, 0.5, 0.0, 1.0]])
     u = np.array([[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]])
     simb = api.MBC_Sim(t, u, np.zeros((2, 2)), 2.0, 8, code="MBC")
