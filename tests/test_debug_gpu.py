@@ -6,6 +6,7 @@
   HTN_DEBUG_EVENT_WAITS=1  the Lanczos driver waits for a completed HIP event per step instead of polling the
                            host-mapped step record; the record must still validate.
 
+(A third child runs the fallback SVD path of the large blocks, HTN_SVD_PAIRS=1, against the default ring kernel.)
 Both are read once per process, so each case runs `python tests/test_debug_gpu.py` as ONE child process (one extra GPU
 process at a time) and must reproduce the in-process run of the same schedule BIT FOR BIT: energies after every sweep
 and the centre Schmidt spectrum.  The schedule covers the one-workgroup SVD, the forced large-block SVD path
@@ -96,6 +97,23 @@ def test_schedule_takes_the_paths_it_is_meant_to(baseline):
 def test_poisoned_pool_changes_nothing(baseline):
     """no kernel consumes memory nobody wrote: with every pool block starting as NaN the run is bit-identical"""
     _same(baseline, _child("HTN_DEBUG_POISON"))
+
+
+def test_pair_visit_svd_path_agrees_with_the_ring_path(baseline):
+    """HTN_SVD_PAIRS=1 sends the large blocks through the multi-launch pair-visit block Jacobi (the fallback for blocks the
+    ring kernel cannot take) instead of the one-launch ring kernel: a different rotation order, the same SVD -- energies to
+    1e-10 relative, Schmidt values to 1e-9 of the sector's largest"""
+    other = _child("HTN_SVD_PAIRS")
+    assert other.keys() == baseline.keys()
+    for name in baseline:
+        Ea = [float.fromhex(x) for x in baseline[name]["E"]]
+        Eb = [float.fromhex(x) for x in other[name]["E"]]
+        assert np.allclose(Ea, Eb, rtol=1e-10, atol=0.0), (name, Ea, Eb)
+        assert baseline[name]["spec"].keys() == other[name]["spec"].keys()
+        for c, va in baseline[name]["spec"].items():
+            a = np.array([float.fromhex(x) for x in va])
+            b = np.array([float.fromhex(x) for x in other[name]["spec"][c]])
+            assert a.shape == b.shape and np.abs(a - b).max() <= 1e-9 * a.max(), (name, c)
 
 
 def test_event_waits_change_nothing(baseline):
