@@ -418,6 +418,172 @@ __device__ __forceinline__ void lds_barrier() {
 // Between panels this is block MODIFIED Gram-Schmidt (every panel sees the updated trailing matrix), whose
 // R factor is backward stable like that of column MGS.  R entries are stored by PHYSICAL column index
 // (X[j][phys k] = conj(r_jk)), so nothing is ever swapped and the row permutation handed on is the identity.
+// ---- trailing update shared between workgroups ----------------------------------------------------------------------
+// The trailing update of a panel (C = Q_p^H A, A <- A - Q_p C on the MFMA pipe) is 55 % of k_qr_large on a 202 x 202 block and
+// runs at the MFMA rate of ONE CU (measured 471 of 860 us; window 81, panel steps 299), 77 % on a 400 x 400 block (3.0 of
+// 3.9 ms).  With NW > 1 workgroups per block (used above 288 columns, see the launch site) the
+// master (role 0) keeps the pivoting and the panel factorisation and publishes, per panel, the panel basis Q_p, the column
+// map and the panel's geometry; every workgroup then updates the 16-column chunks ch with ch % NW == role and the helpers
+// hand back the new column norms.  Everything that crosses workgroups inside the launch follows cdna_hip_programming.md
+// section 6, Guideline 16 (first table row of MI355X_MICROARCH.md "visibility"): every store of shared bytes -- Q_p, the
+// map, the updated columns of A, the rows of R in X, the norms -- is a write-through (sc1) store, every storing wave drains,
+// workgroup barrier, ONE lane raises an epoch with an agent-scope atomic store; the other side polls that word from one lane,
+// workgroup barrier, and every load of shared bytes is an sc1 load.  No placement assumption; polls are bounded (ring_wait_ge).
+typedef unsigned int qr_u4 __attribute__((ext_vector_type(4)));
+struct QrShare {
+    int NW, role;
+    double2* qn;             // [16 * ldq] panel basis (global copy)
+    int* scol;               // [n0] logical -> physical column
+    double* cn2;             // [n0] squared norms the helpers computed (by logical position)
+    int* meta;               // j0, nb_eff, k_first, last_panel, finished
+    unsigned* qflag;         // master -> helpers: number of panels published so far
+    unsigned* hflag;         // [NW]: helper -> master: panels completed
+    unsigned* fail;
+};
+__device__ __forceinline__ bool qr_wait_ge(unsigned* flag, unsigned want, unsigned* fail) {
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 1;; ++spins) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 255u) == 0u) {
+            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (wall_clock64() - t0 > 300000000ll) {             // 3 s of the 100 MHz constant clock
+                __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+template <bool SH>
+__device__ __forceinline__ double2 qr_ld(const double2* base, __amdgpu_buffer_rsrc_t rs, int idx) {
+    if (!SH) return base[idx];
+    const qr_u4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 16, 0, 16);
+    double2 v;
+    __builtin_memcpy(&v, &u, 16);
+    return v;
+}
+template <bool SH>
+__device__ __forceinline__ void qr_st(double2* base, __amdgpu_buffer_rsrc_t rs, int idx, double2 v) {
+    if (!SH) {
+        base[idx] = v;
+        return;
+    }
+    qr_u4 u;
+    __builtin_memcpy(&u, &v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(u, rs, idx * 16, 0, 16);
+}
+
+// one 16-column chunk of the trailing update by one wave: rows j0 .. of R for its columns (-> X), then the columns themselves
+// and their new norms (norm_out[k], LDS for the master, the shared array for a helper)
+template <bool SH>
+__device__ __forceinline__ void qr_trailing_chunk(double2* __restrict__ g0, __amdgpu_buffer_rsrc_t rg, double2* __restrict__ Xg,
+                                                  __amdgpu_buffer_rsrc_t rx, const double2* Qn, int ldq, const int* s_col, int m0,
+                                                  int m0p, int n0, int mp, int j0, int nb_eff, int k_first, int ch, bool last_panel,
+                                                  double* norm_out, bool norm_shared, int lane) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int nks = m0p >> 2;
+    const int k = k_first + 16 * ch + l15;
+    const bool valid = k < n0;
+    const int pk = valid ? s_col[k] : 0;
+    const int abase = pk * m0;
+    d4 cr = {0.0, 0.0, 0.0, 0.0}, ci = {0.0, 0.0, 0.0, 0.0};
+    const double2* qrow = Qn + l15 * ldq + l4;
+    double2 ring[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = 4 * u + l4;
+        ring[u] = (valid && u < nks && i < m0) ? qr_ld<SH>(g0, rg, abase + i) : make_double2(0.0, 0.0);
+    }
+    for (int ks0 = 0; ks0 < nks; ks0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ks = ks0 + u;
+            if (ks < nks) {
+                const double2 b = ring[u];
+                const int inx = 4 * (ks + 4) + l4;
+                ring[u] = (valid && ks + 4 < nks && inx < m0) ? qr_ld<SH>(g0, rg, abase + inx) : make_double2(0.0, 0.0);
+                const double2 qv = qrow[4 * ks];
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.x, b.x, cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.x, b.y, ci, 0, 0, 0);
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.y, b.y, cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-qv.y, b.x, ci, 0, 0, 0);
+            }
+        }
+    }
+    // rows j0 + (l4 + 4 reg) of R, column k
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int t = l4 + 4 * reg;
+        if (valid && t < nb_eff) qr_st<SH>(Xg, rx, (j0 + t) * mp + pk, make_double2(cr[reg], -ci[reg]));
+    }
+    if (last_panel) return;                       // no later panel reads the trailing columns
+    double nrm = 0.0;
+    for (int i0 = 0; i0 < m0p; i0 += 16) {
+        double2 old[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = i0 + l4 + 4 * reg;
+            old[reg] = (valid && i < m0) ? qr_ld<SH>(g0, rg, abase + i) : make_double2(0.0, 0.0);
+        }
+        d4 dr = {0.0, 0.0, 0.0, 0.0}, di = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double2 qa = Qn[(l4 + 4 * kk) * ldq + i0 + l15];
+            dr = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.x, cr[kk], dr, 0, 0, 0);
+            di = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.x, ci[kk], di, 0, 0, 0);
+            dr = __builtin_amdgcn_mfma_f64_16x16x4f64(-qa.y, ci[kk], dr, 0, 0, 0);
+            di = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.y, cr[kk], di, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = i0 + l4 + 4 * reg;
+            if (valid && i < m0) {
+                const double2 x = make_double2(old[reg].x - dr[reg], old[reg].y - di[reg]);
+                qr_st<SH>(g0, rg, abase + i, x);
+                nrm += x.x * x.x + x.y * x.y;
+            }
+        }
+    }
+    nrm += __shfl_xor(nrm, 16, 64);      // over the 4 lanes (l4) that share a column
+    nrm += __shfl_xor(nrm, 32, 64);
+    if (valid && l4 == 0) {
+        if (norm_shared) __hip_atomic_store(norm_out + k, nrm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else norm_out[k] = nrm;
+    }
+}
+
+// a helper workgroup of a block: per published panel, fetch Q_p and the column map, update its chunks, report
+__device__ __forceinline__ void qr_helper(double2* __restrict__ g0, int m0, int n0, int r, double2* __restrict__ Xg, int mp, int* s_col,
+                                          double2* Qn, int tid, const QrShare sh) {
+    __shared__ int s_meta[8];
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m0p = (m0 + 15) & ~15, ldq = m0p + 1;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)g0, 0, m0 * n0 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)Xg, 0, mp * r * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)sh.qn, 0, 16 * ldq * 16, 0x00020000);
+    for (unsigned epoch = 1;; ++epoch) {
+        if (tid == 0) {
+            const bool ok = qr_wait_ge(sh.qflag, epoch, sh.fail);
+            s_meta[5] = ok ? 0 : 1;
+            for (int q = 0; q < 5; ++q) s_meta[q] = ok ? __hip_atomic_load(sh.meta + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+        __syncthreads();
+        const int j0 = s_meta[0], nb_eff = s_meta[1], k_first = s_meta[2];
+        const bool last_panel = s_meta[3] != 0, finished = s_meta[4] != 0 || s_meta[5] != 0;
+        if (finished) break;
+        for (int idx = tid; idx < 16 * ldq; idx += JAC_THREADS) Qn[idx] = qr_ld<true>(sh.qn, rq, idx);
+        for (int k = k_first + tid; k < n0; k += JAC_THREADS) s_col[k] = __hip_atomic_load(sh.scol + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int nchunks = (n0 - k_first + 15) >> 4;
+        for (int q = wave; sh.role + sh.NW * q < nchunks; q += JAC_THREADS / 64)
+            qr_trailing_chunk<true>(g0, rg, Xg, rx, Qn, ldq, s_col, m0, m0p, n0, mp, j0, nb_eff, k_first, sh.role + sh.NW * q, last_panel,
+                                    sh.cn2, true, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(sh.hflag + sh.role, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 #ifdef HTN_QR_PROF          // diagnostic build only (tools/ring_prof.py --qr): 100 MHz ticks per phase of k_qr_large, block 0
 __device__ long long g_qr_prof[8];
 extern "C" int htn_qr_prof_dump(long long* out) {
@@ -431,22 +597,27 @@ extern "C" int htn_qr_prof_dump(long long* out) {
 #define QR_T(var)
 #define QR_ACC(slot, a, b)
 #endif
-template <int EL>
+template <int EL, bool SH>
 __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, int n0, int r,
                                             double2* __restrict__ Xg, int mp, int* s_col, double* s_cn2,
-                                            double* s_piv, double2* Qn, int tid, double cut2) {
+                                            double* s_piv, double2* Qn, int tid, double cut2, const QrShare sh) {
     __shared__ double s_pn[16];
+    __shared__ int s_share_ok;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)g0, 0, m0 * n0 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)Xg, 0, mp * r * 16, 0x00020000);
+    unsigned pub_epoch = 0;
+    if (tid == 0) s_share_ok = 1;
     __shared__ double2 s_r[16][17];      // the panel's own R block, [pivot step][owner wave]; flushed once per panel
     __shared__ int s_pc[16];
     __shared__ int s_pos[16];
     __shared__ int s_nb;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int m0p = (m0 + 15) & ~15, ldq = m0p + 1;
-    for (int idx = tid; idx < mp * r; idx += JAC_THREADS) Xg[idx] = make_double2(0.0, 0.0);
+    for (int idx = tid; idx < mp * r; idx += JAC_THREADS) qr_st<SH>(Xg, rx, idx, make_double2(0.0, 0.0));
     for (int k = wave; k < n0; k += JAC_THREADS / 64) {
         double c = 0.0;
         for (int i = lane; i < m0; i += 64) {
-            const double2 x = g0[(int64_t)k * m0 + i];
+            const double2 x = g0[(int64_t)k * m0 + i];       // (written before this launch: plain loads)
             c += x.x * x.x + x.y * x.y;
         }
         c = wave_sum(c);
@@ -522,7 +693,7 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
 #pragma unroll
         for (int e = 0; e < EL; ++e) {
             const int i = lane + 64 * e;
-            a[e] = (owner && i < m0) ? g0[(int64_t)pc * m0 + i] : make_double2(0.0, 0.0);
+            a[e] = (owner && i < m0) ? qr_ld<SH>(g0, rg, pc * m0 + i) : make_double2(0.0, 0.0);
         }
         if (!owner)                                   // unused panel positions project onto nothing
             for (int i = lane; i < m0p; i += 64) Qn[wave * ldq + i] = make_double2(0.0, 0.0);
@@ -633,7 +804,7 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
         }
         if (tid < nb_eff) s_col[j0 + tid] = s_pos[tid];
         if (tid < 256 && (tid >> 4) < nb_eff && (tid & 15) < nb)      // rows of R before a column's own pivot step: 0
-            Xg[(int64_t)(j0 + (tid >> 4)) * mp + s_pc[tid & 15]] = s_r[tid >> 4][tid & 15];
+            qr_st<SH>(Xg, rx, (j0 + (tid >> 4)) * mp + s_pc[tid & 15], s_r[tid >> 4][tid & 15]);
         __syncthreads();
         QR_T(q4);
         QR_ACC(3, q3, q4);
@@ -641,73 +812,41 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
         const int k_first = j0 + nb;
         const int nchunks = (n0 - k_first + 15) >> 4;
         const bool last_panel = stop || k_first >= r;
-        const int nks = m0p >> 2;
-        for (int ch = wave; ch < nchunks; ch += JAC_THREADS / 64) {
-            const int k = k_first + 16 * ch + l15;
-            const bool valid = k < n0;
-            const int pk = valid ? s_col[k] : 0;
-            double2* __restrict__ ak = g0 + (int64_t)pk * m0;
-            d4 cr = {0.0, 0.0, 0.0, 0.0}, ci = {0.0, 0.0, 0.0, 0.0};
-            const double2* qrow = Qn + l15 * ldq + l4;
-            double2 ring[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = 4 * u + l4;
-                ring[u] = (valid && u < nks && i < m0) ? ak[i] : make_double2(0.0, 0.0);
+        const int NW = SH ? sh.NW : 1;
+        if (SH && nchunks > 0) {
+            // publish the panel: basis, column map of the trailing part, geometry; drain; ONE lane raises the epoch
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)sh.qn, 0, 16 * ldq * 16, 0x00020000);
+            for (int idx = tid; idx < 16 * ldq; idx += JAC_THREADS) qr_st<true>(sh.qn, rq, idx, Qn[idx]);
+            for (int k = k_first + tid; k < n0; k += JAC_THREADS) __hip_atomic_store(sh.scol + k, s_col[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                __hip_atomic_store(sh.meta + 0, j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sh.meta + 1, nb_eff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sh.meta + 2, k_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sh.meta + 3, last_panel ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sh.meta + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            for (int ks0 = 0; ks0 < nks; ks0 += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ks = ks0 + u;
-                    if (ks < nks) {
-                        const double2 b = ring[u];
-                        const int inx = 4 * (ks + 4) + l4;
-                        ring[u] = (valid && ks + 4 < nks && inx < m0) ? ak[inx] : make_double2(0.0, 0.0);
-                        const double2 qv = qrow[4 * ks];
-                        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.x, b.x, cr, 0, 0, 0);
-                        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.x, b.y, ci, 0, 0, 0);
-                        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.y, b.y, cr, 0, 0, 0);
-                        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-qv.y, b.x, ci, 0, 0, 0);
-                    }
-                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ++pub_epoch;
+            if (tid == 0) __hip_atomic_store(sh.qflag, pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int q = wave; NW * q < nchunks; q += JAC_THREADS / 64)            // the master's share: chunks ch with ch % NW == 0
+            qr_trailing_chunk<SH>(g0, rg, Xg, rx, Qn, ldq, s_col, m0, m0p, n0, mp, j0, nb_eff, k_first, NW * q, last_panel, s_cn2, false, lane);
+        if (SH && nchunks > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's own column updates are out before the next panel reads them
+            __syncthreads();
+            if (tid == 0) {
+                bool ok = true;
+                for (int h = 1; h < NW && ok; ++h) ok = qr_wait_ge(sh.hflag + h, pub_epoch, sh.fail);
+                if (!ok) s_share_ok = 0;
             }
-            // rows j0 + (l4 + 4 reg) of R, column k
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int t = l4 + 4 * reg;
-                if (valid && t < nb_eff) Xg[(int64_t)(j0 + t) * mp + pk] = make_double2(cr[reg], -ci[reg]);
+            __syncthreads();
+            if (!s_share_ok) {
+                stop = true;
+            } else if (!last_panel) {
+                for (int k = k_first + tid; k < n0; k += JAC_THREADS)
+                    if (((k - k_first) >> 4) % NW != 0) s_cn2[k] = __hip_atomic_load(sh.cn2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (last_panel) continue;                 // no later panel reads the trailing columns
-            double nrm = 0.0;
-            for (int i0 = 0; i0 < m0p; i0 += 16) {
-                double2 old[4];
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int i = i0 + l4 + 4 * reg;
-                    old[reg] = (valid && i < m0) ? ak[i] : make_double2(0.0, 0.0);
-                }
-                d4 dr = {0.0, 0.0, 0.0, 0.0}, di = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const double2 qa = Qn[(l4 + 4 * kk) * ldq + i0 + l15];
-                    dr = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.x, cr[kk], dr, 0, 0, 0);
-                    di = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.x, ci[kk], di, 0, 0, 0);
-                    dr = __builtin_amdgcn_mfma_f64_16x16x4f64(-qa.y, ci[kk], dr, 0, 0, 0);
-                    di = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.y, cr[kk], di, 0, 0, 0);
-                }
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int i = i0 + l4 + 4 * reg;
-                    if (valid && i < m0) {
-                        const double2 x = make_double2(old[reg].x - dr[reg], old[reg].y - di[reg]);
-                        ak[i] = x;
-                        nrm += x.x * x.x + x.y * x.y;
-                    }
-                }
-            }
-            nrm += __shfl_xor(nrm, 16, 64);      // over the 4 lanes (l4) that share a column
-            nrm += __shfl_xor(nrm, 32, 64);
-            if (valid && l4 == 0) s_cn2[k] = nrm;
         }
         __syncthreads();
         QR_T(q5);
@@ -725,6 +864,15 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
         for (int q = 0; q < 8; ++q) g_qr_prof[q] = qprof[q];
     }
 #endif
+    if (SH) {                  // release the helpers (every path out of the panel loop ends here)
+        if (tid == 0) {
+            __hip_atomic_store(sh.meta + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(sh.qflag, pub_epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_share_ok) rank = -1;
+    }
     for (int i = tid; i < n0; i += JAC_THREADS) s_col[i] = i;      // rows of X are physical columns already
     __syncthreads();
     return rank;
@@ -732,42 +880,52 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
 
 // one workgroup per LARGE block (X = R^H does not fit the LDS window): pivoted QR only; the sweeps follow as
 // multi-launch block Jacobi.  Runs beside k_jacobi_svd (small blocks) on a forked stream.
+#define QR_BOX_BYTES 137728      // per large block: 16 x 513 complex128 (Q_p) | 512 int (column map) | 512 double (norms) | meta
 __global__ __launch_bounds__(JAC_THREADS) void k_qr_large(double2* __restrict__ G, double2* __restrict__ Vj,
                                                           const htn_svd_block* __restrict__ desc,
                                                           const int* __restrict__ large_ids, int* __restrict__ perm,
                                                           double* __restrict__ zero2_out, double cut2,
-                                                          int* __restrict__ rank_host) {
+                                                          int* __restrict__ rank_host, int NW, char* __restrict__ qr_box,
+                                                          unsigned* __restrict__ qr_sync, int nl) {
     extern __shared__ double2 g_lds[];
     __shared__ double s_piv[2];
     __shared__ int s_col[64 * JAC_MAXEL];
     __shared__ double s_cn2[64 * JAC_MAXEL];
-    const htn_svd_block D = desc[large_ids[blockIdx.x]];
-    const int m = D.m, n = D.n, m0 = D.pad, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = blockIdx.x / NW, role = blockIdx.x % NW;
+    const htn_svd_block D = desc[large_ids[li]];
+    const int m = D.m, n = D.n, m0 = D.pad, tid = threadIdx.x;
     const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
     const int mp = gsx * ((m + gsx - 1) / gsx);
     double2* __restrict__ X = Vj + D.v_off;
+    QrShare sh;
+    sh.NW = NW, sh.role = role;
+    char* box = qr_box + (size_t)li * QR_BOX_BYTES;
+    sh.qn = (double2*)box;
+    sh.scol = (int*)(box + 16 * 513 * 16);
+    sh.cn2 = (double*)(box + 16 * 513 * 16 + 512 * 4);
+    sh.meta = (int*)(box + 16 * 513 * 16 + 512 * 4 + 512 * 8);
+    sh.qflag = qr_sync + li * 8;
+    sh.hflag = qr_sync + li * 8 + 1;
+    sh.fail = qr_sync + nl * 8;
+    if (role > 0) {
+        qr_helper(G + D.g_off, m0, m, n, X, mp, s_col, (double2*)g_lds, tid, sh);
+        return;
+    }
     int rank;
-    if (m0 <= 256) rank = qrcp_blocked<4>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2);
-    else rank = qrcp_blocked<8>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2);
+    if (NW > 1) {
+        if (m0 <= 256) rank = qrcp_blocked<4, true>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh);
+        else rank = qrcp_blocked<8, true>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh);
+    } else {
+        if (m0 <= 256) rank = qrcp_blocked<4, false>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh);
+        else rank = qrcp_blocked<8, false>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh);
+    }
     if (tid == 0) {
-        rank_host[blockIdx.x] = rank;               // host-pinned: the host sizes the Jacobi tournament with it
+        rank_host[li] = rank;                       // host-pinned: the host sizes the Jacobi tournament with it (< 0: a hand-off timed out)
+        // threshold for "numerically zero" columns of X = R^H: |X|_F^2 = |G0|_F^2 (the QR preserves it), summed in fixed order above
+        zero2_out[li] = s_piv[1];
         __threadfence_system();
     }
-    // |X|_F^2 -> threshold for "numerically zero" columns (fixed-order sums: bit-reproducible)
-    double f = 0.0;
-    for (int idx = tid; idx < mp * n; idx += JAC_THREADS) {
-        const double2 x = X[idx];
-        f += x.x * x.x + x.y * x.y;
-    }
-    f = wave_sum(f);
-    if (lane == 0) s_cn2[wave] = f;
-    __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
-        for (int q = 0; q < JAC_THREADS / 64; ++q) t += s_cn2[q];
-        zero2_out[blockIdx.x] = 1e-30 * t;
-    }
-    for (int i = tid; i < m; i += JAC_THREADS) perm[blockIdx.x * 64 * JAC_MAXEL + i] = s_col[i];
+    for (int i = tid; i < m; i += JAC_THREADS) perm[li * 64 * JAC_MAXEL + i] = s_col[i];
 }
 
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_svd(double2* __restrict__ G, double2* __restrict__ Vj,
@@ -1752,6 +1910,8 @@ struct JacScratch {
     size_t ring_sync_bytes = 0;
     void* ring_mbox = nullptr;          // ring Jacobi: mailboxes
     size_t ring_mbox_bytes = 0;
+    void* qr_box = nullptr;             // k_qr_large with helper workgroups: per-block panel basis / column map / norms (sc1 traffic)
+    size_t qr_box_bytes = 0;
     void* ring_items = nullptr;         // ring Jacobi: work items (device) and their pinned staging
     void* ring_items_h = nullptr;
     size_t ring_items_cap = 0;
@@ -1771,6 +1931,7 @@ struct JacScratch {
         if (dev) (void)hipFree(dev);
         if (pinned) (void)hipHostFree(pinned);
         if (flags) (void)hipHostFree(flags);
+        if (qr_box) (void)hipFree(qr_box);
         if (ring_sync) (void)hipFree(ring_sync);
         if (ring_mbox) (void)hipFree(ring_mbox);
         if (ring_items) (void)hipFree(ring_items);
@@ -1926,7 +2087,8 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     const size_t off_ids = 0, off_slot = off_ids + sizeof(int) * nl, off_perm = off_slot + sizeof(int) * n_blocks;
     const size_t off_zero = off_perm + sizeof(int) * nl * 64 * JAC_MAXEL;
     const size_t off_ratio = (off_zero + sizeof(double) * nl + 7) / 8 * 8, off_done = off_ratio + 8 * nl;
-    const size_t off_sw = off_done + sizeof(int) * nl, off_items = (off_sw + sizeof(int) * nl + 31) / 32 * 32;
+    const size_t off_sw = off_done + sizeof(int) * nl, off_qsync = off_sw + sizeof(int) * nl;      // qsync: 8 words per block + failure word
+    const size_t off_items = (off_qsync + sizeof(unsigned) * (8 * (size_t)nl + 8) + 31) / 32 * 32;
     const size_t dev_bytes = off_items + sizeof(JacPairItem) * n_items_max;
     JacScratch* jsp = nullptr;
     if (js_get(st, &jsp)) return 1;
@@ -1942,6 +2104,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     unsigned long long* d_ratio = (unsigned long long*)(d + off_ratio);
     int* d_done = (int*)(d + off_done);
     int* d_sw = (int*)(d + off_sw);
+    unsigned* d_qsync = (unsigned*)(d + off_qsync);
     JacPairItem* d_items = (JacPairItem*)(d + off_items);
     // pinned staging (host -> device): [items | ids | slot of every block]; device -> host flags (their own coherent
     // block, read by the host only behind a completed event): [active count per sweep | rank per large block]
@@ -1962,7 +2125,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     // every small copy / fill is a separate blit launch on the stream: they are enqueued BEFORE the QR (nothing here
     // depends on it unless a rank cut sizes the tournament), merged where the regions are contiguous
     HIP_TRY(hipMemcpyAsync(d_ids, h_ids, sizeof(int) * (nl + n_blocks), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(d_ratio, 0, 16 * (size_t)nl, st));          // ratio (8 nl) | done (4 nl) | sweeps (4 nl)
+    HIP_TRY(hipMemsetAsync(d_ratio, 0, 16 * (size_t)nl + sizeof(unsigned) * (8 * (size_t)nl + 8), st));      // ratio (8 nl) | done (4 nl) | sweeps (4 nl) | qsync
     const double cut2 = g_jac_cut * g_jac_cut;
     std::vector<int> n_eff(nl);
     for (int li = 0; li < nl; ++li) n_eff[li] = desc_host[large[li]].n;
@@ -2040,8 +2203,27 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         int max_m0 = 0;
         for (int li = 0; li < nl; ++li) max_m0 = std::max(max_m0, (int)desc_host[large[li]].pad);
         const size_t qr_lds = (size_t)16 * (((max_m0 + 15) & ~15) + 1) * sizeof(double2);
-        hipLaunchKernelGGL(k_qr_large, dim3(nl), dim3(JAC_THREADS), qr_lds, st, (double2*)G, (double2*)Vj, desc, d_ids,
-                           d_perm, d_zero, cut2, d_rank);
+        // workgroups per block: the master + helpers for the trailing update (all co-resident: they wait for each other)
+        int max_n0 = 0;
+        for (int li = 0; li < nl; ++li) max_n0 = std::max(max_n0, (int)desc_host[large[li]].m);
+        static const bool qr_single = htn_env_flag("HTN_QR_SINGLE");
+        // Measured (tools/ring_prof.py, HTN_QR_PROF): every shared byte goes to memory and comes back from memory (sc1), so a
+        // chunk's operand loads wait ~2 us each instead of an L2 hit: 202 x 202 blocks LOSE (trailing 483 -> 655 us with four
+        // workgroups), 400 x 400 blocks gain (3.0 -> 2.3 ms).  Helpers only where the trailing update dominates by far.
+        int NW = (qr_single || max_n0 <= 288) ? 1 : 4;
+        NW = std::max(1, std::min(NW, std::max(1, std::min(g_js.cu_count > 0 ? g_js.cu_count : 256, 256)) / std::max(nl, 1)));
+        if (NW > 1) {
+            const size_t need = (size_t)nl * QR_BOX_BYTES;
+            if (need > g_js.qr_box_bytes) {
+                if (g_js.qr_box) HIP_TRY(hipFree(g_js.qr_box));
+                g_js.qr_box = nullptr, g_js.qr_box_bytes = 0;
+                HIP_TRY(hipMalloc(&g_js.qr_box, need * 2));
+                g_js.qr_box_bytes = need * 2;
+                if (htn_debug_poison()) HIP_TRY(hipMemset(g_js.qr_box, 0xFF, need * 2));
+            }
+        }
+        hipLaunchKernelGGL(k_qr_large, dim3(nl * NW), dim3(JAC_THREADS), qr_lds, st, (double2*)G, (double2*)Vj, desc, d_ids,
+                           d_perm, d_zero, cut2, d_rank, NW, (char*)g_js.qr_box, d_qsync, nl);
     }
     if (cut2 > 0.0) {        // the tournament is sized by the ranks the QR found: wait for them (one sync per call)
         HIP_TRY(hipEventRecord(g_js.ev_sweep[0], st));
@@ -2097,6 +2279,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         HIP_TRY(htn_stream_spin(st));      // the staging blocks are reused by the next call; the sweep counts are read below
         int used = 0;
         for (int li = 0; li < nl; ++li) {
+            if (h_rank[li] < 0) return fail_msg("htn_jacobi_svd_z: a hand-off of the multi-workgroup QR timed out");
             if (h_ring_sw[li] <= 0 && n_eff[li] >= 2) return fail_msg("htn_jacobi_svd_z: a hand-off of the ring Jacobi kernel timed out");
             used = std::max(used, (int)h_ring_sw[li]);
         }
