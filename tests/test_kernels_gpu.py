@@ -261,7 +261,7 @@ def test_large_block_svd_result_does_not_depend_on_the_sweep_hint(hip_ops):
     not followed by an empty one): singular values, vectors and the reported sweep count are bit-identical for no hint,
     the right hint, a hint that is too small (extra sweeps are then enqueued one at a time) and one that is too large"""
     rng = np.random.default_rng(21)
-    shapes = [(230, 230), (300, 170)]
+    shapes = [(230, 230), (300, 170), (330, 310)]        # (310 columns: the pivoted QR runs with helper workgroups, above 288)
     desc = np.zeros(len(shapes), dtype=abi.SVD_DT)
     go = vo = so = 0
     mats = []
@@ -279,7 +279,7 @@ def test_large_block_svd_result_does_not_depend_on_the_sweep_hint(hip_ops):
     for hint in (0, None, 2, 30):
         dG = src.clone()
         dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
-        used = hip_ops.jacobi_svd(dG, dV, dS, d_desc, len(shapes), 300, 40, 1e-14, info, desc_host=desc,
+        used = hip_ops.jacobi_svd(dG, dV, dS, d_desc, len(shapes), 330, 40, 1e-14, info, desc_host=desc,
                                   sweeps_hint=used0 if hint is None else hint)
         if used0 is None:
             used0 = used
