@@ -112,7 +112,7 @@ int htn_scale_inv_sqrt_z(void* dst, const void* src, const void* nrm2, int64_t n
  * Stands in for: KrylovKit.eigsolve(H_eff, x0, 1, :SR, Lanczos(krylovdim, tol, eager=true)) as called by
  * MPSKit's two-site update (reached from src/HubbardFunctions.jl:1010): orthonormal Krylov
  * basis kept in full, explicit two-pass reorthogonalisation, tridiagonal problem solved after every expansion,
- * stop when |beta_j y_j| < tol, restart from the Ritz vector at krylovdim.
+ * stop when |beta_j y_j| < tol, restart from the Ritz vector at krylovdim (2 <= krylovdim <= 31).
  * V: (krylovdim + 2) * n complex128; on entry V[0:n] = start vector, on exit V[0:n] = normalised Ritz vector.
  * exchange (may be NULL): called on the host after each matvec has been ENQUEUED, with the device pointer of y;
  * the multi-GPU host uses it to enqueue an RCCL all-reduce of y on the same stream (zero_y = 1 then clears y
@@ -143,10 +143,13 @@ int htn_lanczos_z(const htn_gemm_launch* stages_host, int32_t n_stages, int32_t 
  * Vj + v_off[i] (ld = n_i).  The caller stages M or M^H (htn_batched_copy_z) so that the isometry the
  * sweep direction needs is the normalised G*J itself; the other factor is then a plain GEMM with M.
  * desc: device array of htn_svd_block, desc_host: the same array in host memory (may be NULL: then every block
- * runs on ONE CU; with it, QRCP blocks larger than one CU's LDS take the large-block path: panel-blocked pivoted QR,
- * then block Jacobi whose panel-pair visits run on many CUs, one kernel launch per tournament round, convergence
- * decided on the device; the small blocks run beside it on an internal second stream that joins `stream` before the
- * call returns; the call blocks the host until the sweeps have converged, results stay on the device);
+ * runs on ONE CU; with it, QRCP blocks larger than one CU's LDS take the large-block path: panel-blocked pivoted QR
+ * (helper workgroups share its trailing update above 288 columns), then the ring block Jacobi -- all sweeps in ONE launch,
+ * every block on several CUs whose LDS-resident column panels are handed round inside the launch (write-through stores +
+ * epoch flags; bounded waits: a time-out is reported as an error of this call), convergence decided on the device; the
+ * small blocks run beside it on an internal second stream that joins `stream` before the call returns; the call blocks
+ * the host until everything has converged, results stay on the device.  Blocks the ring cannot take fall back to the
+ * pair-visit block Jacobi of ABI 2 (one launch per tournament round; sweeps_hint bounds its speculative enqueue));
  * max_m_host = max_i max(m_i, pad_i) (<= 512 in this version).
  * info_dev[i] receives the sweep count (<0: not converged).  A sweep ends the iteration when the largest squared
  * cosine it SAW before rotating was <= max(tol^2, 0.1 tol) (quadratic convergence: it leaves < tol^2 behind). */
