@@ -1567,10 +1567,60 @@ __device__ __forceinline__ double ring_rotate(double2 (&a)[E], const double2 (&b
     return ratio2;
 }
 
+// The same rotation in SCALED ("fast") form for the cross rounds: a column is kept as (scale, stored vector) with true column =
+// scale * stored.  With the true g = sa sb g_st the update  [a' b'] = [a b] [[c, c q g], [-c q conj(g), c]]  becomes
+//   a_st' = a_st - (q sb^2 conj(g_st)) b_st,   b_st' = b_st + (q sa^2 g_st) a_st,   sa' = c sa,   sb' = c sb
+// -- 8 real multiply-adds per element pair instead of 12 (the factor c moves into the two scales).  Scales start at 1 in
+// every round and are applied when the round ends (at most w factors c >= 1/sqrt 2 accumulate: no range issue).
+template <int GS, int E>
+__device__ __forceinline__ double ring_rotate_scaled(double2 (&a)[E], const double2 (&b)[E], double2* b_out, double& aa, double& bb,
+                                                     double& sa, double& sb, double tol2, double zero2) {
+    double gr = 0.0, gi = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        gr = fma(a[e].x, b[e].x, fma(a[e].y, b[e].y, gr));      // conj(a_st) * b_st
+        gi = fma(a[e].x, b[e].y, fma(-a[e].y, b[e].x, gi));
+    }
+    gr = group_sum<GS>(gr);
+    gi = group_sum<GS>(gi);
+    if (aa <= zero2 || bb <= zero2) return 0.0;
+    const double ss = sa * sb;
+    const double g2 = ss * ss * fma(gr, gr, gi * gi);           // |g|^2 of the true columns
+    const double ab = aa * bb;
+    if (g2 == 0.0) return 0.0;
+    const double ratio2 = g2 * __builtin_amdgcn_rcp(ab);
+    if (g2 <= tol2 * ab) return ratio2;
+    const double h = bb - aa;
+    const double w2 = fma(h, h, 4.0 * g2);
+    const double w = w2 * __builtin_amdgcn_rsq(w2);
+    double q = 2.0 * __builtin_amdgcn_rcp(fabs(h) + w);
+    q = h >= 0.0 ? q : -q;
+    const double c = fast_rsq(fma(q * q, g2, 1.0));
+    aa = fma(-q, g2, aa);
+    bb = fma(q, g2, bb);
+    const double qb = q * sb * sb, qa = q * sa * sa;
+    const double mur = qb * gr, mui = -qb * gi;                 // mu = q sb^2 conj(g_st)
+    const double nur = qa * gr, nui = qa * gi;                  // nu = q sa^2 g_st
+    sa *= c;
+    sb *= c;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        double2 nb;
+        nb.x = fma(-nui, a[e].y, fma(nur, a[e].x, b[e].x));
+        nb.y = fma(nui, a[e].x, fma(nur, a[e].y, b[e].y));
+        b_out[GS * e] = nb;
+        double x = fma(-mur, b[e].x, a[e].x), y = fma(-mur, b[e].y, a[e].y);
+        a[e].x = fma(mui, b[e].y, x);
+        a[e].y = fma(-mui, b[e].x, y);
+    }
+    return ratio2;
+}
+
 // all nt x nb cross pairs of the two resident panels: group g owns T column g in registers (and its tracked norm), B columns
 // pass through LDS, their tracked norms through bnorm[]
 template <int GS, int E>
-__device__ __forceinline__ double ring_cross(double2* T, double2* B, int nt, int nb, int tid, double tol2, double zero2, double* bnorm) {
+__device__ __forceinline__ double ring_cross(double2* T, double2* B, int nt, int nb, int tid, double tol2, double zero2, double* bnorm,
+                                             double* bscale) {
     constexpr int mp = GS * E;
     const int grp = tid / GS, sub = tid % GS;
     const int wm = nt > nb ? nt : nb;
@@ -1578,16 +1628,16 @@ __device__ __forceinline__ double ring_cross(double2* T, double2* B, int nt, int
     if (nt == 0 || nb == 0) return ratio;                      // (uniform over the workgroup)
     const bool own = grp < nt;
     double2 a[E];
-    double aa = 0.0;
+    double aa = 0.0, sa = 1.0;
     if (own) {
 #pragma unroll
         for (int e = 0; e < E; ++e) a[e] = T[grp * mp + sub + GS * e];
-        double sa = 0.0;
+        double t = 0.0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) sa = fma(a[e].x, a[e].x, fma(a[e].y, a[e].y, sa));
-        aa = group_sum<GS>(sa);
+        for (int e = 0; e < E; ++e) t = fma(a[e].x, a[e].x, fma(a[e].y, a[e].y, t));
+        aa = group_sum<GS>(t);
     }
-    if (grp < nb) {            // exact squared norm of B column grp
+    if (grp < nb) {            // exact squared norm of B column grp; its scale starts at 1
         const double2* bc = B + grp * mp + sub;
         double sb = 0.0;
 #pragma unroll
@@ -1596,7 +1646,10 @@ __device__ __forceinline__ double ring_cross(double2* T, double2* B, int nt, int
             sb = fma(v.x, v.x, fma(v.y, v.y, sb));
         }
         sb = group_sum<GS>(sb);
-        if (sub == 0) bnorm[grp] = sb;
+        if (sub == 0) {
+            bnorm[grp] = sb;
+            bscale[grp] = 1.0;
+        }
     }
     __syncthreads();
     for (int s = 0; s < wm; ++s) {
@@ -1607,16 +1660,30 @@ __device__ __forceinline__ double ring_cross(double2* T, double2* B, int nt, int
             double2* bc = B + j * mp + sub;
 #pragma unroll
             for (int e = 0; e < E; ++e) b[e] = bc[GS * e];
-            double bb = bnorm[j];
-            const double rr = ring_rotate<GS, E, false>(a, b, bc, aa, bb, tol2, zero2);
+            double bb = bnorm[j], sb = bscale[j];
+            const double rr = ring_rotate_scaled<GS, E>(a, b, bc, aa, bb, sa, sb, tol2, zero2);
             ratio = rr > ratio ? rr : ratio;
-            if (sub == 0) bnorm[j] = bb;
+            if (sub == 0) {
+                bnorm[j] = bb;
+                bscale[j] = sb;
+            }
         }
         __syncthreads();
     }
-    if (own) {
+    if (own) {                 // the scales come out with the columns: T from registers, B in place
 #pragma unroll
-        for (int e = 0; e < E; ++e) T[grp * mp + sub + GS * e] = a[e];
+        for (int e = 0; e < E; ++e) T[grp * mp + sub + GS * e] = make_double2(a[e].x * sa, a[e].y * sa);
+    }
+    if (grp < nb) {
+        const double sb = bscale[grp];
+        if (sb != 1.0) {
+            double2* bc = B + grp * mp + sub;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double2 v = bc[GS * e];
+                bc[GS * e] = make_double2(v.x * sb, v.y * sb);
+            }
+        }
     }
     __syncthreads();
     return ratio;
@@ -1740,7 +1807,7 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
             const int par = (int)(epoch & 1u);
             const int nt = ncols(s_top[k]), nb = ncols(s_bot[k]);
             RING_T(p0);
-            const double rr = ring_cross<GS, E>(bufT, bufB, nt, nb, tid, tol2, zero2, s_bnorm);
+            const double rr = ring_cross<GS, E>(bufT, bufB, nt, nb, tid, tol2, zero2, s_bnorm, s_bnorm + RING_THREADS / 16);
             ratio = rr > ratio ? rr : ratio;
             RING_T(p1);
             RING_ACC(0, p0, p1);
@@ -1872,7 +1939,7 @@ __global__ __launch_bounds__(RING_THREADS) void k_jacobi_ring(RingArgs A) {
     __shared__ int s_top[RING_MAX_P], s_bot[RING_MAX_P];
     __shared__ unsigned long long s_rbits;
     __shared__ int s_ok;
-    __shared__ double s_bnorm[RING_THREADS / 16];      // tracked squared norms of the bottom panel's columns
+    __shared__ double s_bnorm[2 * (RING_THREADS / 16)];      // tracked squared norms | scales of the bottom panel's columns
     const RingItem it = A.items[blockIdx.x];
     const htn_svd_block D = A.desc[A.large_ids[it.li]];
     const int m = D.m;
