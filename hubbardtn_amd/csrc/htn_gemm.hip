@@ -207,8 +207,6 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_MINOCC) void k_grouped_gemm_z
     const bool presplit = T.pad[1] != 0;
     const htn_seg* __restrict__ sg = segs + T.seg_begin;
     const int n_staged = n_gemm < GEMM_DESC_MAX ? n_gemm : GEMM_DESC_MAX;
-    for (int i = tid; i < 4 * n_staged; i += 64 * GEMM_WAVES) ((uint4*)s_desc)[i] = ((const uint4*)sg)[i];
-    __syncthreads();
     const int orow = wr * 16 + l15;                // this lane's outputs are C[r0 + orow][c0 + wc 16 + l4 + 4 r]
     // operand row / column of this lane, clamped to the tile edge (see load_ops)
     const int arow = T.row0 + (orow < T.m ? orow : T.m - 1), bcol = T.col0 + (wc * 16 + l15 < T.n ? wc * 16 + l15 : T.n - 1);
@@ -216,18 +214,35 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_MINOCC) void k_grouped_gemm_z
     d4 acc_re = {0.0, 0.0, 0.0, 0.0};
     d4 acc_im = {0.0, 0.0, 0.0, 0.0};
 
+    // Start-up chain: tile record -> segment descriptors -> operands are three dependent memory round trips (~1.3 us each)
+    // during which every resident workgroup of the launch idles at once.  The descriptor staging (vector loads -> LDS) is
+    // issued first, but the wave's FIRST descriptor comes straight through the scalar cache in parallel with it and the first
+    // slab's operand loads are in flight before the staging barrier; only the later descriptors wait for the LDS copy.
+    for (int i = tid; i < 4 * n_staged; i += 64 * GEMM_WAVES) ((uint4*)s_desc)[i] = ((const uint4*)sg)[i];
+    Cursor cn = {0, 0};
+    bool vn = false;
+    Ops r[GEMM_DEPTH];
+    if (n_gemm > 0) {
+        advance(cn, grp, sg, n_gemm, presplit);
+        vn = cn.s < n_gemm;
+        const htn_seg S0 = sg[vn ? cn.s : n_gemm - 1];      // (scalar loads; always a real descriptor: load_ops loads from it)
+        load_ops(r[0], bufs, S0, cn, vn, arow, bcol, l4);
+    }
+    __syncthreads();
+
     // ---- K loop: group g takes slabs g, g + ngrp, ... of the tile's flat slab sequence.  GEMM_DEPTH register sets
     // rotate: the loads of the next GEMM_DEPTH - 1 slabs are in flight while the current slab's 16 MFMAs issue (an
     // operand fetch out of L2 / Infinity Cache takes 1.5-2 us, a slab's MFMAs 0.43 us) ----
     if (n_gemm > 0) {
         // The segment DESCRIPTOR of the slab after the one being fetched is read (from LDS) one step ahead (Sn).
-        Cursor cn = {0, 0};
-        advance(cn, grp, sg, n_gemm, presplit);
-        bool vn = cn.s < n_gemm;
-        htn_seg Sn = read_seg(s_desc, sg, vn ? cn.s : n_gemm - 1, n_staged);      // always a real descriptor: load_ops loads from it
-        Ops r[GEMM_DEPTH];
+        htn_seg Sn = read_seg(s_desc, sg, vn ? cn.s : n_gemm - 1, n_staged);
+        if (vn) {
+            advance(cn, ngrp, sg, n_gemm, presplit);
+            vn = cn.s < n_gemm;
+            if (vn) Sn = read_seg(s_desc, sg, cn.s, n_staged);
+        }
 #pragma unroll
-        for (int d = 0; d < GEMM_DEPTH; ++d) {
+        for (int d = 1; d < GEMM_DEPTH; ++d) {
             load_ops(r[d], bufs, Sn, cn, vn, arow, bcol, l4);
             if (vn) {
                 advance(cn, ngrp, sg, n_gemm, presplit);
