@@ -10,6 +10,8 @@
 // 64 partials with a butterfly), so results are bit-reproducible run to run and rank to rank.
 #include <math.h>
 
+#include <chrono>
+
 #include <map>
 #include <memory>
 #include <mutex>
@@ -640,6 +642,10 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
                        (LanRecord*)nullptr, (const double2*)nullptr, (const double2*)nullptr, 0ull);
     double mv_ms = 0.0;
     int nmv = 0, n_timed = 0;
+    static const bool dbg_timers = getenv("HTN_DEBUG_HOST_TIMERS") != nullptr;
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_enq = 0.0, t_wait = 0.0, t_host = 0.0;
+    const double t_begin = now_us();
     double theta = 0.0, res = 0.0, beta = 0.0, amax = 0.0;
     std::vector<double> y;
     for (int restart = 0; restart <= max_restart; ++restart) {
@@ -647,15 +653,22 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         // Software pipeline of depth 1: step j+1 is enqueued BEFORE the host waits for step j's record, so the
         // GPU never idles during the host's convergence test.  If step j converges, step j+1 was speculative:
         // it only wrote Krylov row j+2, device scalars j+1 and record slot j+1, which nothing reads afterwards.
+        double tq = now_us();
         if (enqueue_step(0, true)) return 1;
+        t_enq += now_us() - tq;
         ++nmv;
         for (int j = 0; j < kd; ++j) {
             if (j + 1 < kd) {
+                tq = now_us();
                 if (enqueue_step(j + 1, false)) return 1;
+                t_enq += now_us() - tq;
                 ++nmv;
             }
             double a1 = 0.0, a2 = 0.0, nn = 0.0;
+            tq = now_us();
             if (wait_step(j, &a1, &a2, &nn)) return 1;
+            t_wait += now_us() - tq;
+            tq = now_us();
             if (timed_step[j]) {
                 float ms = 0.f;
                 HIP_TRY(htn_event_spin(R->ev_mv1[j]));
@@ -671,6 +684,7 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
             res = fabs(beta * y.back());
             amax = std::max(amax, std::max(fabs(alpha), beta));
             // invariant subspace: beta negligible RELATIVE to the scale of the tridiagonal matrix
+            t_host += now_us() - tq;
             if (res < tol || beta < 1e-14 * std::max(amax, 1e-300) || j == kd - 1) break;
             betas.push_back(beta);
         }
@@ -689,6 +703,9 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         if (res < tol || beta < 1e-14 * std::max(amax, 1e-300)) break;
     }
     HIP_TRY(hipGetLastError());
+    if (dbg_timers)
+        fprintf(stderr, "lanczos n=%lld: %d matvecs in %.1f us: enqueue %.1f, waiting for records %.1f, tridiagonal %.1f\n", (long long)n, nmv,
+                now_us() - t_begin, t_enq, t_wait, t_host);
     *eig_host = theta;
     *n_matvec_host = nmv;
     *residual_host = res;
