@@ -181,12 +181,14 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
     const double s = s_scale;
     for (int i = wave; i < nvec; i += DOT_THREADS / 64) {
         double2 r = reduce_partials(partial_in + (int64_t)i * DOT_BLOCKS, lane);
-        const double f = (norm_prev && i == last) ? s * s : s;
+        const bool raw_row = norm_prev && i == last;   // the row this coefficient multiplies is still unnormalised
+        const double f = raw_row ? s * s : s;
         r.x *= f;
         r.y *= f;
         if (lane == 0) {
-            cs[i][0] = r.x;
-            cs[i][1] = r.y;
+            // the update below uses the rows as stored: the raw row's coefficient carries its factor s
+            cs[i][0] = raw_row ? r.x * s : r.x;
+            cs[i][1] = raw_row ? r.y * s : r.y;
             if (blockIdx.x == 0 && i == c_index) *c_out = r;
         }
     }
@@ -206,17 +208,9 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
             const int i = c < nvec ? c : nvec - 1;
             v[c] = V[(int64_t)i * ldv + j];
         }
-        if (fix) {                                    // (uniform) normalise the newest row on the way and write it back
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                if (c >= last) {                      // c == last, and the clamped copies beyond it (their coefficients are 0)
-                    v[c].x *= s;
-                    v[c].y *= s;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (c == last) V[(int64_t)last * ldv + j] = v[c];
+        if (fix) {                                    // (uniform) the newest row goes back normalised; v[] keeps it RAW: its factor s
+            const double2 vl = V[(int64_t)last * ldv + j];      // sits in its coefficient (above) and in its dot (below) -- no per-row select
+            V[(int64_t)last * ldv + j] = make_double2(vl.x * s, vl.y * s);
         }
         double sr = 0.0, si = 0.0;
 #pragma unroll
@@ -250,6 +244,10 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
         for (int q = 0; q < DOT_THREADS / 64; ++q) {
             r += red[q][tid][0];
             m += red[q][tid][1];
+        }
+        if (fix && tid == last) {                     // <s raw, w> = s <raw, w>
+            r *= s;
+            m *= s;
         }
         partial_out[(int64_t)tid * DOT_BLOCKS + blockIdx.x] = make_double2(r, m);
     }
