@@ -35,15 +35,18 @@ __device__ __forceinline__ double2 reduce_partials(const double2* __restrict__ p
     return make_double2(wave_sum(sr), wave_sum(si));
 }
 
-// partial[i * DOT_BLOCKS + b] = sum over slice b of conj(V_i) * w.  ONE WAVE per slice: every lane issues
-// all its loads back to back (latency, not bandwidth, bounds this kernel at |theta| ~ 10^5) and the only
-// reduction is the in-wave butterfly -- no LDS stage, no barrier.  CH = vectors per pass (compile time, so the
-// loads are unconditional and can all be in flight; indices past nvec are clamped and their sums discarded).
+// partial[i * DOT_BLOCKS + b] = sum over slice b of conj(V_i) * w.  Every lane issues all its loads back to back (latency,
+// not bandwidth, bounds this kernel at |theta| ~ 10^5); the reductions are the in-wave butterfly plus one fixed-order sum over
+// the four waves of a slice.  CH = vectors per pass (compile time, so the loads are unconditional and can all be in flight;
+// indices past nvec are clamped and their sums discarded).
 template <int CH>
-__global__ __launch_bounds__(64) void k_dots_partial(const double2* __restrict__ V, int64_t ldv, int nvec,
-                                                     const double2* __restrict__ w, int64_t n,
-                                                     double2* __restrict__ partial) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_dots_partial(const double2* __restrict__ V, int64_t ldv, int nvec,
+                                                      const double2* __restrict__ w, int64_t n,
+                                                      double2* __restrict__ partial) {
+    // FOUR waves per slice (round 3; one before): a wave keeps CH + 1 loads in flight per lane and the kernel is bound by the
+    // latency of that one batch -- 256 waves on 256 CUs moved 4.7 TB/s; the quarter slices are summed in fixed wave order
+    __shared__ double red[4][CH][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t per = (n + DOT_BLOCKS - 1) / DOT_BLOCKS;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(64) void k_dots_partial(const double2* __restrict__
         double sr[CH], si[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) sr[c] = si[c] = 0.0;
-        for (int64_t j = lo + lane; j < hi; j += 64) {
+        for (int64_t j = lo + threadIdx.x; j < hi; j += 256) {
             const double2 b = w[j];
             double2 a[CH];
 #pragma unroll
@@ -69,17 +72,28 @@ __global__ __launch_bounds__(64) void k_dots_partial(const double2* __restrict__
         for (int c = 0; c < CH; ++c) {
             const double r = wave_sum(sr[c]);
             const double m = wave_sum(si[c]);
-            if (lane == 0 && i0 + c < nvec) partial[(int64_t)(i0 + c) * DOT_BLOCKS + blockIdx.x] = make_double2(r, m);
+            if (lane == 0) {
+                red[wave][c][0] = r;
+                red[wave][c][1] = m;
+            }
         }
+        __syncthreads();
+        if (threadIdx.x < CH && i0 + (int)threadIdx.x < nvec) {
+            const int c = threadIdx.x;
+            const double r = (red[0][c][0] + red[1][c][0]) + (red[2][c][0] + red[3][c][0]);
+            const double m = (red[0][c][1] + red[1][c][1]) + (red[2][c][1] + red[3][c][1]);
+            partial[(int64_t)(i0 + c) * DOT_BLOCKS + blockIdx.x] = make_double2(r, m);
+        }
+        __syncthreads();
     }
 }
 
 static void launch_dots_partial(const double2* V, int64_t ldv, int nvec, const double2* w, int64_t n, double2* partial,
                                 hipStream_t st) {
-    if (nvec <= 4) hipLaunchKernelGGL(k_dots_partial<4>, dim3(DOT_BLOCKS), dim3(64), 0, st, V, ldv, nvec, w, n, partial);
-    else if (nvec <= 8) hipLaunchKernelGGL(k_dots_partial<8>, dim3(DOT_BLOCKS), dim3(64), 0, st, V, ldv, nvec, w, n, partial);
-    else if (nvec <= 16) hipLaunchKernelGGL(k_dots_partial<16>, dim3(DOT_BLOCKS), dim3(64), 0, st, V, ldv, nvec, w, n, partial);
-    else hipLaunchKernelGGL(k_dots_partial<32>, dim3(DOT_BLOCKS), dim3(64), 0, st, V, ldv, nvec, w, n, partial);
+    if (nvec <= 4) hipLaunchKernelGGL(k_dots_partial<4>, dim3(DOT_BLOCKS), dim3(256), 0, st, V, ldv, nvec, w, n, partial);
+    else if (nvec <= 8) hipLaunchKernelGGL(k_dots_partial<8>, dim3(DOT_BLOCKS), dim3(256), 0, st, V, ldv, nvec, w, n, partial);
+    else if (nvec <= 16) hipLaunchKernelGGL(k_dots_partial<16>, dim3(DOT_BLOCKS), dim3(256), 0, st, V, ldv, nvec, w, n, partial);
+    else hipLaunchKernelGGL(k_dots_partial<32>, dim3(DOT_BLOCKS), dim3(256), 0, st, V, ldv, nvec, w, n, partial);
 }
 
 // one wave per vector: out[i] = sum_b partial[i][b]
