@@ -104,7 +104,10 @@ __global__ void k_dots_reduce(const double2* __restrict__ partial, int nvec, dou
 }
 
 // fused: c = reduce(partial); w += sign * V c ; norm_partial[b] = |w_new slice|^2 ; block 0 writes c[c_index]
-// to *c_out (a device scalar: the step's last kernel, k_scale_by_norm, hands it to the host inside the step record)
+// to *c_out (a device scalar: the next matvec launch hands it to the host inside the step record).  CH = vectors per pass
+// (compile time): all basis loads of an element are in flight together (the earlier version walked them eight at a time, one
+// memory round trip per group of eight).
+template <int CH>
 __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__ w, const double2* __restrict__ V,
                                                            int64_t ldv, int nvec,
                                                            const double2* __restrict__ partial,
@@ -128,21 +131,19 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__
     const int64_t hi = lo + per < n ? lo + per : n;
     double nn = 0.0;
     for (int64_t j = lo + tid; j < hi; j += DOT_THREADS) {
-        double sr = 0.0, si = 0.0;
-        for (int i0 = 0; i0 < nvec; i0 += 8) {           // 8 independent loads in flight per step
-            double2 v[8];
+        double2 v[CH];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int i = i0 + c < nvec ? i0 + c : nvec - 1;
-                v[c] = V[(int64_t)i * ldv + j];
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                sr += cs[i0 + c][0] * v[c].x - cs[i0 + c][1] * v[c].y;
-                si += cs[i0 + c][0] * v[c].y + cs[i0 + c][1] * v[c].x;
-            }
+        for (int c = 0; c < CH; ++c) {
+            const int i = c < nvec ? c : nvec - 1;
+            v[c] = V[(int64_t)i * ldv + j];
         }
         double2 x = w[j];
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {                    // cs[c] = 0 beyond nvec
+            sr += cs[c][0] * v[c].x - cs[c][1] * v[c].y;
+            si += cs[c][0] * v[c].y + cs[c][1] * v[c].x;
+        }
         x.x += sign * sr;
         x.y += sign * si;
         w[j] = x;
@@ -157,6 +158,18 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__
         for (int q = 0; q < DOT_THREADS / 64; ++q) t += red[q];
         norm_partial[blockIdx.x] = t;
     }
+}
+
+static void launch_axpy_norm(double2* w, const double2* V, int64_t ldv, int nvec, const double2* partial, double2* c_out, int c_index,
+                             double sign, int64_t n, double* norm_partial, hipStream_t st) {
+#define HTN_AN(CHV)                                                                                                       \
+    hipLaunchKernelGGL(k_axpy_norm<CHV>, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, ldv, nvec, partial, c_out, c_index, \
+                       sign, n, norm_partial)
+    if (nvec <= 4) HTN_AN(4);
+    else if (nvec <= 8) HTN_AN(8);
+    else if (nvec <= 16) HTN_AN(16);
+    else HTN_AN(32);
+#undef HTN_AN
 }
 
 // first Gram-Schmidt update FUSED with the second pass's dots: c = reduce(partial_in); w += sign * V c; and, while the
@@ -607,8 +620,7 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         // two-pass classical Gram-Schmidt in three passes over the basis: dots | update + dots (fused) | update + norm
         launch_dots_partial(V, n, j + 1, w, n, partial, st);
         launch_axpy_dots(w, V, n, j + 1, partial, c1 + j, j, -1.0, n, partial2, first ? (const double*)nullptr : norm_partial, st);
-        hipLaunchKernelGGL(k_axpy_norm, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, n, j + 1, partial2, c2 + j, j,
-                           -1.0, n, norm_partial);
+        launch_axpy_norm(w, V, n, j + 1, partial2, c2 + j, j, -1.0, n, norm_partial, st);
         if (j == kd - 1) {
             hipLaunchKernelGGL(k_publish_record, dim3(1), dim3(64), 0, st, (const double*)norm_partial, (const double2*)(c1 + j),
                                (const double2*)(c2 + j), R->d_rec + j, step_serial[j]);
