@@ -214,6 +214,10 @@ struct Tasks {
     std::vector<htn_seg> segs;
     int32_t nsegs = 0;
     int64_t flops = 0;           // algorithmic complex128 flops (8 per MAC) of the GEMM segments
+    // optional placement hint for balance_tiles: ascending start offsets (in the output buffer) of groups of output blocks
+    // whose tiles read the same operands (H_eff apply: one group per coupled-sector matrix of theta); tiles of a group are
+    // steered to one XCD so that its L2 fetches those operands once.  Empty: tiles are grouped by output row strip.
+    std::vector<int64_t> group_bounds;
 };
 
 // Load balance of one grouped-GEMM launch (HIP backend): the launch is bound by its longest tile's dependent K loop,

@@ -517,6 +517,13 @@ int balance_tiles(Tasks& t, int n_cus) {
     static const int env_capk = getenv("HTN_GEMM_CAPK") ? atoi(getenv("HTN_GEMM_CAPK")) : 0;
     static const int env_xcd = getenv("HTN_GEMM_XCD") ? atoi(getenv("HTN_GEMM_XCD")) : 1;
     static const int env_layers = getenv("HTN_GEMM_LAYERS") ? atoi(getenv("HTN_GEMM_LAYERS")) : GEMM_RESIDENT;
+    // Grouped (sector-run -> XCD) placement of the H_eff apply's tiles: OFF by default.  Measured at chi = 1024 (tools/
+    // gemm_groups_ab.sh, PMC FETCH_SIZE pass + bench.py): fabric traffic per launch 23.5 MB -> 12.7 MB (3.3x -> 1.78x the
+    // algorithmic bytes), launch time 22.1 -> 23.6 us.  The re-reads are served by the Infinity Cache and are not what binds the
+    // kernel; concentrating a sector's tiles on one XCD costs more (per-XCD composition of long and short tiles) than the
+    // shorter operand latency buys.  HTN_GEMM_GROUPS=1 switches it on.
+    static const int env_groups = getenv("HTN_GEMM_GROUPS") ? atoi(getenv("HTN_GEMM_GROUPS")) : 0;
+    const bool use_groups = env_groups && !t.group_bounds.empty();
     auto slabs = [](const htn_tile& T) { return std::max(0, T.seg_count - T.pad[0]); };
     auto ways = [](const htn_tile& T) { return 4 / ((T.m > 16 ? 2 : 1) * (T.n > 16 ? 2 : 1)); };
     auto load = [&](const htn_tile& T) { const int g = ways(T); return (slabs(T) + g - 1) / g + 1; };   // + 1: prologue / epilogue
@@ -603,32 +610,120 @@ int balance_tiles(Tasks& t, int n_cus) {
     std::vector<std::vector<int>> cu_tiles((size_t)n_cus);
     std::unordered_map<Key, int, KeyHash> home;
     int next = 0;
-    for (int l = 0; l < n_layers; ++l) {
-        const int cnt = std::min(n_cus, n - next);
-        // the XCD of every part of this layer: its strip's home if that XCD still has room in the layer
-        std::vector<int> room(NX, per), xs(cnt);
-        if (cnt < n_cus)            // last, partial layer: launch positions are filled in order, XCD x gets ceil / floor
-            for (int x = 0; x < NX; ++x) room[x] = cnt / NX + (x < cnt % NX ? 1 : 0);
-        for (int j = 0; j < cnt; ++j) {
-            const htn_tile& T = out[order[next + j]];
-            const Key k = mk(T.buf_c, (int32_t)(T.c_off & 0x7fffffff), (int32_t)(T.c_off >> 31), T.row0);
-            auto it = home.find(k);
-            int x = it == home.end() ? -1 : it->second;
-            if (x < 0 || room[x] == 0) {
-                int y = -1;
-                for (int c = 0; c < NX; ++c)
-                    if (room[c] > 0 && (y < 0 || x_load[c] < x_load[y])) y = c;
-                if (x < 0) home[k] = y;
-                x = y;
-            }
-            --room[x];
-            xs[j] = x;
-            x_load[x] += load(T);
+    std::vector<std::vector<int>> layers;       // tile indices of every resident layer, with the XCD each one goes to
+    std::vector<std::vector<int>> layer_x;
+    std::vector<char> used((size_t)n, 0);
+    if (use_groups && NX > 1) {
+        // GROUPED placement (H_eff apply): the coupled-sector matrices of the output are cut, in their sorted order, into NX
+        // contiguous runs of about equal load and every run is given to one XCD -- a tile reads the theta matrix of its own
+        // sector, those of the neighbouring sectors (the two-site terms move one electron across the centre bond) and the
+        // environment blocks of its sector's outer labels, so neighbours in the sorted order share most of what they read and
+        // each XCD's L2 fetches it once.  Every XCD then fills its share of each layer from its OWN longest-first list; what
+        // an XCD cannot place (its list ran out) is filled from the others' leftovers at the end.
+        const int ng = (int)t.group_bounds.size() + 1;
+        std::vector<int64_t> gload((size_t)ng, 0);
+        std::vector<int> grp((size_t)n);
+        int64_t tot = 0;
+        for (int i = 0; i < n; ++i) {
+            grp[i] = (int)(std::upper_bound(t.group_bounds.begin(), t.group_bounds.end(), out[i].c_off) - t.group_bounds.begin());
+            gload[grp[i]] += load(out[i]);
+            tot += load(out[i]);
         }
+        // all tiles in the order (group, block, row strip, column): cut into NX runs of equal load (a large sector is shared
+        // by two neighbouring XCDs rather than unbalancing one)
+        std::vector<int> seq(n);
+        for (int i = 0; i < n; ++i) seq[i] = i;
+        std::stable_sort(seq.begin(), seq.end(), [&](int a, int b) {
+            if (grp[a] != grp[b]) return grp[a] < grp[b];
+            if (out[a].c_off != out[b].c_off) return out[a].c_off < out[b].c_off;
+            if (out[a].row0 != out[b].row0) return out[a].row0 < out[b].row0;
+            return out[a].col0 < out[b].col0;
+        });
+        std::vector<int> thome((size_t)n, 0);
+        {
+            // weight of a tile in the XCD partition: its slab units plus a fixed cost (start-up, reduction, store) that
+            // the per-CU balance above can afford to underestimate (it averages out over a CU's six tiles) but a partition
+            // by sector cannot: the outer sectors are all small tiles
+            static const int pw = getenv("HTN_GEMM_PW") ? atoi(getenv("HTN_GEMM_PW")) : 3;
+            auto wgt = [&](int i) { return (int64_t)load(out[i]) - 1 + pw; };
+            int64_t wtot = 0, acc = 0;
+            for (int i = 0; i < n; ++i) wtot += wgt(i);
+            for (int q = 0; q < n; ++q) {
+                const int i = seq[q];
+                const int64_t mid = acc + wgt(i) / 2;
+                thome[i] = (int)std::min<int64_t>(NX - 1, mid * NX / std::max<int64_t>(wtot, 1));
+                acc += wgt(i);
+            }
+        }
+        (void)gload;
+        std::vector<std::vector<int>> xq(NX);       // per XCD, longest first (order[] is sorted)
+        for (int j = 0; j < n; ++j) xq[thome[order[j]]].push_back(order[j]);
+        std::vector<size_t> xpos(NX, 0);
+        for (int l = 0; l < n_layers; ++l) {
+            const int cnt = std::min(n_cus, n - next);
+            std::vector<int> room(NX, per);
+            if (cnt < n_cus)
+                for (int x = 0; x < NX; ++x) room[x] = cnt / NX + (x < cnt % NX ? 1 : 0);
+            std::vector<int> li, lx;
+            for (int x = 0; x < NX; ++x)
+                while (room[x] > 0 && xpos[x] < xq[x].size()) {
+                    li.push_back(xq[x][xpos[x]++]);
+                    lx.push_back(x);
+                    --room[x];
+                }
+            for (int x = 0; x < NX; ++x)                     // slots an XCD could not fill itself: the longest leftover of the fullest queue
+                while (room[x] > 0) {
+                    int y = -1;
+                    for (int c = 0; c < NX; ++c)
+                        if (xpos[c] < xq[c].size() && (y < 0 || xq[c].size() - xpos[c] > xq[y].size() - xpos[y])) y = c;
+                    if (y < 0) break;
+                    li.push_back(xq[y][xpos[y]++]);
+                    lx.push_back(x);
+                    --room[x];
+                }
+            for (int i : li) used[i] = 1;
+            next += (int)li.size();
+            layers.push_back(li);
+            layer_x.push_back(lx);
+        }
+    } else {
+        for (int l = 0; l < n_layers; ++l) {
+            const int cnt = std::min(n_cus, n - next);
+            // the XCD of every part of this layer: its strip's home if that XCD still has room in the layer
+            std::vector<int> room(NX, per), xs(cnt), li(cnt);
+            if (cnt < n_cus)            // last, partial layer: launch positions are filled in order, XCD x gets ceil / floor
+                for (int x = 0; x < NX; ++x) room[x] = cnt / NX + (x < cnt % NX ? 1 : 0);
+            for (int j = 0; j < cnt; ++j) {
+                const htn_tile& T = out[order[next + j]];
+                const Key k = mk(T.buf_c, (int32_t)(T.c_off & 0x7fffffff), (int32_t)(T.c_off >> 31), T.row0);
+                auto it = home.find(k);
+                int x = it == home.end() ? -1 : it->second;
+                if (x < 0 || room[x] == 0) {
+                    int y = -1;
+                    for (int c = 0; c < NX; ++c)
+                        if (room[c] > 0 && (y < 0 || x_load[c] < x_load[y])) y = c;
+                    if (x < 0) home[k] = y;
+                    x = y;
+                }
+                --room[x];
+                xs[j] = x;
+                li[j] = order[next + j];
+                used[li[j]] = 1;
+                x_load[x] += load(T);
+            }
+            next += cnt;
+            layers.push_back(li);
+            layer_x.push_back(xs);
+        }
+    }
+    for (size_t l = 0; l < layers.size(); ++l) {
         // inside the XCD: longest part of the layer to the least loaded CU that has no part of this layer yet
+        std::vector<int> idx(layers[l].size());
+        for (size_t j = 0; j < idx.size(); ++j) idx[j] = (int)j;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return load(out[layers[l][a]]) > load(out[layers[l][b]]); });
         std::vector<char> taken((size_t)n_cus, 0);
-        for (int j = 0; j < cnt; ++j) {
-            const int i = order[next + j], x = xs[j];
+        for (int j : idx) {
+            const int i = layers[l][j], x = layer_x[l][j];
             int best = -1;
             for (int k = 0; k < per; ++k) {
                 const int c = k * NX + x;
@@ -638,7 +733,6 @@ int balance_tiles(Tasks& t, int n_cus) {
             cu_tiles[best].push_back(i);
             cu_load[best] += load(out[i]);
         }
-        next += cnt;
     }
     // launch order: CUs that take part in the last (possibly partial) layer come first inside their XCD -- the rotation of
     // an XCD restarts at its first CU with every layer
@@ -656,7 +750,8 @@ int balance_tiles(Tasks& t, int n_cus) {
                 const int c = cus[x][k];
                 if ((int)cu_tiles[c].size() > l) fin.push_back(out[cu_tiles[c][l]]);
             }
-    for (int j = next; j < n; ++j) fin.push_back(out[order[j]]);
+    for (int j = 0; j < n; ++j)
+        if (!used[order[j]]) fin.push_back(out[order[j]]);
     t.tiles.swap(fin);
     t.ntiles = (int32_t)t.tiles.size();
     return ws;
@@ -755,6 +850,7 @@ void plan_apply(const Mpo& mpo, const ThetaLayout& tl, const EnvLayout& Ll, cons
     out.has_z = !zblocks.empty();
     if (out.has_z) tz.finalize(out.tz);
     ty.finalize(out.ty);
+    for (const auto& M : tl.mats) out.ty.group_bounds.push_back(M.off);      // placement hint: one group per coupled-sector matrix of y
     out.zsize = zoff;
     out.nterms = nterms;
 }
