@@ -455,3 +455,43 @@ def test_grouped_gemm_split_k_across_workgroups_matches_numpy(hip_ops, seed, nbl
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     tickets = hip_ops.to_host(hip_ops._ws)[:abi.WS_TICKET_ELEMS].view(np.int32)
     assert not tickets.any()
+
+
+def test_ring_jacobi_many_uneven_blocks_in_several_batches(hip_ops):
+    """the one-launch ring block Jacobi under uneven load: 18 blocks between 100 and 430 columns in one call need more CU
+    slots than the chip has (the launch is cut into batches of co-resident workgroups), blocks of 100 columns run beside
+    blocks of 430, the 16-lane and the 64-lane forms and the helper-workgroup QR side by side with the one-CU kernel of
+    the small blocks.  Every block must come back as a right-singular-vector matrix times Sigma of ITS matrix."""
+    rng = np.random.default_rng(29)
+    shapes = [(430, 420), (420, 430), (400, 410), (415, 400), (300, 310), (330, 300), (310, 320), (305, 300), (200, 210), (220, 200),
+              (202, 202), (190, 230), (128, 120), (100, 140), (130, 110), (150, 100), (60, 70), (30, 30)]
+    desc = np.zeros(len(shapes), dtype=abi.SVD_DT)
+    go = vo = so = 0
+    mats = []
+    for i, (m0, n0) in enumerate(shapes):
+        r = min(m0, n0)
+        desc[i] = (go, vo, so, n0, r, abi.SVD_QRCP, m0)
+        U, _ = np.linalg.qr(_rand_z(rng, m0 * r).reshape(m0, r))
+        W, _ = np.linalg.qr(_rand_z(rng, n0 * r).reshape(n0, r))
+        s = 10.0 ** (-9 * np.arange(r) / max(r - 1, 1)) * (1.0 + 0.3 * i)
+        mats.append((U * s) @ W.conj().T)
+        go, vo, so = go + m0 * n0, vo + ((n0 + 63) // 64 * 64) * r, so + r
+    dG = hip_ops.to_device(np.concatenate([M.T.reshape(-1) for M in mats]))
+    dV, dS, info = hip_ops.zeros_z(vo), hip_ops.empty_f64(so), hip_ops.empty_i32(len(shapes))
+    used = hip_ops.jacobi_svd(dG, dV, dS, hip_ops.to_device(desc), len(shapes), 430, 40, 1e-14, info, desc_host=desc)
+    Gp, S, inf = hip_ops.to_host(dG), hip_ops.to_host(dS), hip_ops.to_host(info)
+    assert inf.min() >= 0 and inf.max() <= 13 and 3 <= used <= 13, (inf, used)
+    for i, (m0, n0) in enumerate(shapes):
+        d = desc[i]
+        r = min(m0, n0)
+        out = Gp[d["g_off"]:d["g_off"] + n0 * r].reshape(r, n0).T
+        s = S[d["s_off"]:d["s_off"] + r]
+        ref = np.linalg.svd(mats[i], compute_uv=False)
+        order = np.argsort(-s)
+        assert np.abs(s[order] - ref).max() <= 1e-13 * ref[0], i
+        big = ref > 1e-6 * ref[0]
+        assert np.abs(s[order][big] / ref[big] - 1).max() < 1e-8, i
+        live = s > 1e-12 * ref[0]
+        Viso = out[:, live] / s[live]
+        assert np.abs(Viso.conj().T @ Viso - np.eye(live.sum())).max() < 1e-12, i
+        assert np.abs(np.linalg.norm(mats[i] @ Viso, axis=0) - s[live]).max() <= 1e-12 * ref[0], i
