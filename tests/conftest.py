@@ -16,7 +16,7 @@ def pytest_configure(config):
 # A red run must say as much as possible as early as possible (pytest -x stops at the first failure): the cheap,
 # diagnostic tests run first -- kernels vs numpy / LAPACK, then the debug-switch runs, the engine vs oracle / ED, the API,
 # IDMRG2 -- and the long full-size trajectories last.  Files not named here keep their place in front.
-_ORDER = ["test_kernels_gpu", "test_debug_gpu", "test_engine_gpu", "test_api_gpu", "test_idmrg_gpu", "test_fullsize_gpu"]
+_ORDER = ["test_kernels_gpu", "test_debug_gpu", "test_engine_gpu", "test_dist_gpu", "test_api_gpu", "test_idmrg_gpu", "test_fullsize_gpu"]
 
 
 def pytest_collection_modifyitems(session, config, items):
