@@ -23,6 +23,25 @@
 #define DOT_THREADS 256       // threads of the axpy / scale kernels
 #define DOT_CHUNK 32          // vectors handled per pass over the slice of w (krylovdim + 1 <= 31 by default)
 
+// vectors per pass are a compile-time count (all loads of an element in flight at once); rows past nvec are clamped re-reads
+// of the last row, which cost real cache traffic -- so the count comes in steps of four (nvec = 17 under a 32-wide
+// instantiation took 22 us where 16 rows took 15).  Threads per workgroup (TH) are a template parameter too, but only 256 is
+// dispatched: 1024 threads (a slice of 667 elements at chi = 1024 in one step per thread instead of three) changed no
+// kernel's duration -- the 4.5-5 us of the small-j kernels are launch + one round trip + the end-of-kernel write-back,
+// whatever the thread count (measured, round 3).
+#define HTN_CH_DISPATCH(nvec, per, LAUNCH)          \
+    do {                                            \
+        if ((nvec) <= 4) LAUNCH(4, 256);            \
+        else if ((nvec) <= 8) LAUNCH(8, 256);       \
+        else if ((nvec) <= 12) LAUNCH(12, 256);     \
+        else if ((nvec) <= 16) LAUNCH(16, 256);     \
+        else if ((nvec) <= 20) LAUNCH(20, 256);     \
+        else if ((nvec) <= 24) LAUNCH(24, 256);     \
+        else if ((nvec) <= 28) LAUNCH(28, 256);     \
+        else LAUNCH(32, 256);                       \
+    } while (0)
+static inline int64_t dot_slice(int64_t n) { return (n + DOT_BLOCKS - 1) / DOT_BLOCKS; }
+
 // sum of the DOT_BLOCKS partials of one vector by one wave, fixed order
 __device__ __forceinline__ double2 reduce_partials(const double2* __restrict__ p, int lane) {
     double sr = 0.0, si = 0.0;
@@ -39,13 +58,13 @@ __device__ __forceinline__ double2 reduce_partials(const double2* __restrict__ p
 // not bandwidth, bounds this kernel at |theta| ~ 10^5); the reductions are the in-wave butterfly plus one fixed-order sum over
 // the four waves of a slice.  CH = vectors per pass (compile time, so the loads are unconditional and can all be in flight;
 // indices past nvec are clamped and their sums discarded).
-template <int CH>
-__global__ __launch_bounds__(256) void k_dots_partial(const double2* __restrict__ V, int64_t ldv, int nvec,
+template <int CH, int TH>
+__global__ __launch_bounds__(TH) void k_dots_partial(const double2* __restrict__ V, int64_t ldv, int nvec,
                                                       const double2* __restrict__ w, int64_t n,
                                                       double2* __restrict__ partial) {
-    // FOUR waves per slice (round 3; one before): a wave keeps CH + 1 loads in flight per lane and the kernel is bound by the
-    // latency of that one batch -- 256 waves on 256 CUs moved 4.7 TB/s; the quarter slices are summed in fixed wave order
-    __shared__ double red[4][CH][2];
+    // TH / 64 waves per slice: a wave keeps CH + 1 loads in flight per lane and the kernel is bound by the latency of that
+    // one batch -- 256 waves on 256 CUs moved 4.7 TB/s; the waves' shares are summed in fixed wave order
+    __shared__ double red[TH / 64][CH][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t per = (n + DOT_BLOCKS - 1) / DOT_BLOCKS;
     const int64_t lo = (int64_t)blockIdx.x * per;
@@ -54,7 +73,7 @@ __global__ __launch_bounds__(256) void k_dots_partial(const double2* __restrict_
         double sr[CH], si[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) sr[c] = si[c] = 0.0;
-        for (int64_t j = lo + threadIdx.x; j < hi; j += 256) {
+        for (int64_t j = lo + threadIdx.x; j < hi; j += TH) {
             const double2 b = w[j];
             double2 a[CH];
 #pragma unroll
@@ -80,8 +99,12 @@ __global__ __launch_bounds__(256) void k_dots_partial(const double2* __restrict_
         __syncthreads();
         if (threadIdx.x < CH && i0 + (int)threadIdx.x < nvec) {
             const int c = threadIdx.x;
-            const double r = (red[0][c][0] + red[1][c][0]) + (red[2][c][0] + red[3][c][0]);
-            const double m = (red[0][c][1] + red[1][c][1]) + (red[2][c][1] + red[3][c][1]);
+            double r = 0.0, m = 0.0;
+#pragma unroll
+            for (int q = 0; q < TH / 64; ++q) {
+                r += red[q][c][0];
+                m += red[q][c][1];
+            }
             partial[(int64_t)(i0 + c) * DOT_BLOCKS + blockIdx.x] = make_double2(r, m);
         }
         __syncthreads();
@@ -90,10 +113,9 @@ __global__ __launch_bounds__(256) void k_dots_partial(const double2* __restrict_
 
 static void launch_dots_partial(const double2* V, int64_t ldv, int nvec, const double2* w, int64_t n, double2* partial,
                                 hipStream_t st) {
-    if (nvec <= 4) hipLaunchKernelGGL(k_dots_partial<4>, dim3(DOT_BLOCKS), dim3(256), 0, st, V, ldv, nvec, w, n, partial);
-    else if (nvec <= 8) hipLaunchKernelGGL(k_dots_partial<8>, dim3(DOT_BLOCKS), dim3(256), 0, st, V, ldv, nvec, w, n, partial);
-    else if (nvec <= 16) hipLaunchKernelGGL(k_dots_partial<16>, dim3(DOT_BLOCKS), dim3(256), 0, st, V, ldv, nvec, w, n, partial);
-    else hipLaunchKernelGGL(k_dots_partial<32>, dim3(DOT_BLOCKS), dim3(256), 0, st, V, ldv, nvec, w, n, partial);
+#define HTN_DP(CHV, THV) hipLaunchKernelGGL((k_dots_partial<CHV, THV>), dim3(DOT_BLOCKS), dim3(THV), 0, st, V, ldv, nvec, w, n, partial)
+    HTN_CH_DISPATCH(nvec, dot_slice(n), HTN_DP);
+#undef HTN_DP
 }
 
 // one wave per vector: out[i] = sum_b partial[i][b]
@@ -107,16 +129,16 @@ __global__ void k_dots_reduce(const double2* __restrict__ partial, int nvec, dou
 // to *c_out (a device scalar: the next matvec launch hands it to the host inside the step record).  CH = vectors per pass
 // (compile time): all basis loads of an element are in flight together (the earlier version walked them eight at a time, one
 // memory round trip per group of eight).
-template <int CH>
-__global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__ w, const double2* __restrict__ V,
+template <int CH, int TH>
+__global__ __launch_bounds__(TH) void k_axpy_norm(double2* __restrict__ w, const double2* __restrict__ V,
                                                            int64_t ldv, int nvec,
                                                            const double2* __restrict__ partial,
                                                            double2* __restrict__ c_out, int c_index, double sign,
                                                            int64_t n, double* __restrict__ norm_partial) {
     __shared__ double cs[64][2];
-    __shared__ double red[DOT_THREADS / 64];
+    __shared__ double red[TH / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = wave; i < nvec; i += DOT_THREADS / 64) {
+    for (int i = wave; i < nvec; i += TH / 64) {
         const double2 r = reduce_partials(partial + (int64_t)i * DOT_BLOCKS, lane);
         if (lane == 0) {
             cs[i][0] = r.x;
@@ -130,7 +152,7 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
     double nn = 0.0;
-    for (int64_t j = lo + tid; j < hi; j += DOT_THREADS) {
+    for (int64_t j = lo + tid; j < hi; j += TH) {
         double2 v[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -155,20 +177,17 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_norm(double2* __restrict__
     if (tid == 0) {
         double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < DOT_THREADS / 64; ++q) t += red[q];
+        for (int q = 0; q < TH / 64; ++q) t += red[q];
         norm_partial[blockIdx.x] = t;
     }
 }
 
 static void launch_axpy_norm(double2* w, const double2* V, int64_t ldv, int nvec, const double2* partial, double2* c_out, int c_index,
                              double sign, int64_t n, double* norm_partial, hipStream_t st) {
-#define HTN_AN(CHV)                                                                                                       \
-    hipLaunchKernelGGL(k_axpy_norm<CHV>, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, ldv, nvec, partial, c_out, c_index, \
+#define HTN_AN(CHV, THV)                                                                                                    \
+    hipLaunchKernelGGL((k_axpy_norm<CHV, THV>), dim3(DOT_BLOCKS), dim3(THV), 0, st, w, V, ldv, nvec, partial, c_out, c_index, \
                        sign, n, norm_partial)
-    if (nvec <= 4) HTN_AN(4);
-    else if (nvec <= 8) HTN_AN(8);
-    else if (nvec <= 16) HTN_AN(16);
-    else HTN_AN(32);
+    HTN_CH_DISPATCH(nvec, dot_slice(n), HTN_AN);
 #undef HTN_AN
 }
 
@@ -181,15 +200,15 @@ static void launch_axpy_norm(double2* w, const double2* V, int64_t ldv, int nvec
 // that row anyway, so it does the previous step's normalisation on the way: s = 1 / beta, the row is written back as
 // v = s raw, w is taken as s w, and the dots of K2 (taken with the raw row and the raw w) become c_i = s P_i (i < nvec-1),
 // c_last = s^2 P_last.  The separate scale kernel of every step is gone; its record is published by the next matvec launch.
-template <int CH>
-__global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__ w, double2* __restrict__ V,
+template <int CH, int TH>
+__global__ __launch_bounds__(TH) void k_axpy_dots(double2* __restrict__ w, double2* __restrict__ V,
                                                            int64_t ldv, int nvec,
                                                            const double2* __restrict__ partial_in,
                                                            double2* __restrict__ c_out, int c_index, double sign,
                                                            int64_t n, double2* __restrict__ partial_out,
-                                                           const double* __restrict__ norm_prev) {
+                                                           const double* __restrict__ norm_prev, int upd0) {
     __shared__ double cs[64][2];
-    __shared__ double red[DOT_THREADS / 64][CH][2];
+    __shared__ double red[TH / 64][CH][2];
     __shared__ double s_scale;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int last = nvec - 1;
@@ -206,8 +225,10 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
     }
     __syncthreads();
     const double s = s_scale;
-    for (int i = wave; i < nvec; i += DOT_THREADS / 64) {
-        double2 r = reduce_partials(partial_in + (int64_t)i * DOT_BLOCKS, lane);
+    // partial_in holds the dots of rows upd0 .. nvec-1 only (the three-term first pass: upd0 = nvec - 2); the rows below
+    // take no part in this update (coefficient 0) but do in the dots taken on the way
+    for (int i = upd0 + wave; i < nvec; i += TH / 64) {
+        double2 r = reduce_partials(partial_in + (int64_t)(i - upd0) * DOT_BLOCKS, lane);
         const bool raw_row = norm_prev && i == last;   // the row this coefficient multiplies is still unnormalised
         const double f = raw_row ? s * s : s;
         r.x *= f;
@@ -219,7 +240,7 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
             if (blockIdx.x == 0 && i == c_index) *c_out = r;
         }
     }
-    if (tid >= nvec && tid < 64) cs[tid][0] = cs[tid][1] = 0.0;
+    if ((tid >= nvec || tid < upd0) && tid < 64) cs[tid][0] = cs[tid][1] = 0.0;
     __syncthreads();
     const bool fix = norm_prev != nullptr;
     const int64_t per = (n + DOT_BLOCKS - 1) / DOT_BLOCKS;
@@ -228,7 +249,7 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
     double ar[CH], ai[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) ar[c] = ai[c] = 0.0;
-    for (int64_t j = lo + tid; j < hi; j += DOT_THREADS) {
+    for (int64_t j = lo + tid; j < hi; j += TH) {
         double2 v[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
     if (tid < CH && tid < nvec) {                     // fixed order over the 4 waves: deterministic
         double r = 0.0, m = 0.0;
 #pragma unroll
-        for (int q = 0; q < DOT_THREADS / 64; ++q) {
+        for (int q = 0; q < TH / 64; ++q) {
             r += red[q][tid][0];
             m += red[q][tid][1];
         }
@@ -281,14 +302,12 @@ __global__ __launch_bounds__(DOT_THREADS) void k_axpy_dots(double2* __restrict__
 }
 
 static void launch_axpy_dots(double2* w, double2* V, int64_t ldv, int nvec, const double2* partial_in, double2* c_out,
-                             int c_index, double sign, int64_t n, double2* partial_out, const double* norm_prev, hipStream_t st) {
-#define HTN_AD(CHV)                                                                                              \
-    hipLaunchKernelGGL(k_axpy_dots<CHV>, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, w, V, ldv, nvec, partial_in, c_out, \
-                       c_index, sign, n, partial_out, norm_prev)
-    if (nvec <= 4) HTN_AD(4);
-    else if (nvec <= 8) HTN_AD(8);
-    else if (nvec <= 16) HTN_AD(16);
-    else HTN_AD(32);
+                             int c_index, double sign, int64_t n, double2* partial_out, const double* norm_prev, int upd0,
+                             hipStream_t st) {
+#define HTN_AD(CHV, THV)                                                                                           \
+    hipLaunchKernelGGL((k_axpy_dots<CHV, THV>), dim3(DOT_BLOCKS), dim3(THV), 0, st, w, V, ldv, nvec, partial_in, c_out, \
+                       c_index, sign, n, partial_out, norm_prev, upd0)
+    HTN_CH_DISPATCH(nvec, dot_slice(n), HTN_AD);
 #undef HTN_AD
 }
 
@@ -577,6 +596,7 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
     LanRes* R = nullptr;
     if (lan_res_get(st, &R)) return 1;
     const bool event_waits = htn_debug_event_waits();
+    static const bool full_first_pass = htn_env_flag("HTN_LANCZOS_FULL_FIRST_PASS");
 
     bool timed_step[LAN_SLOTS] = {false};
     unsigned long long step_serial[LAN_SLOTS] = {0};
@@ -617,9 +637,16 @@ extern "C" int htn_lanczos_z(const htn_gemm_launch* stages, int32_t n_stages, in
         if (matvec(vj, w, first ? nullptr : &pub)) return 1;
         if (timed) HIP_TRY(hipEventRecord(R->ev_mv1[j], st));
         if (!first && event_waits) HIP_TRY(hipEventRecord(R->ev_done[j - 1], st));
-        // two-pass classical Gram-Schmidt in three passes over the basis: dots | update + dots (fused) | update + norm
-        launch_dots_partial(V, n, j + 1, w, n, partial, st);
-        launch_axpy_dots(w, V, n, j + 1, partial, c1 + j, j, -1.0, n, partial2, first ? (const double*)nullptr : norm_partial, st);
+        // Orthogonalisation in three kernels and TWO passes over the basis.  First the three-term part: dots with V[j-1]
+        // and V[j] only, w' = w - V[j-1] c - V[j] c (against a basis that is orthonormal to rounding every other component
+        // of H v_j is O(eps |H|): <v_i, H v_j> = conj(<v_j, H v_i>) and H v_i has no component along v_j for j > i + 1);
+        // the kernel that makes w' takes the dots of w' with ALL rows on the way, and the last kernel subtracts those --
+        // a full classical Gram-Schmidt pass whose coefficients are O(eps |H|) and whose result is orthogonal to eps |w'|,
+        // which is what the second pass of a two-pass scheme delivers.  (Until round 3 the first pass was a full one as well:
+        // one more read of the whole basis per step; HTN_LANCZOS_FULL_FIRST_PASS=1 brings it back for comparison.)
+        const int upd0 = full_first_pass || j < 2 ? 0 : j - 1;
+        launch_dots_partial(V + (int64_t)upd0 * n, n, j + 1 - upd0, w, n, partial, st);
+        launch_axpy_dots(w, V, n, j + 1, partial, c1 + j, j, -1.0, n, partial2, first ? (const double*)nullptr : norm_partial, upd0, st);
         launch_axpy_norm(w, V, n, j + 1, partial2, c2 + j, j, -1.0, n, norm_partial, st);
         if (j == kd - 1) {
             hipLaunchKernelGGL(k_publish_record, dim3(1), dim3(64), 0, st, (const double*)norm_partial, (const double2*)(c1 + j),
