@@ -1456,15 +1456,32 @@ __device__ __forceinline__ bool ring_wait_ge(unsigned* flag, unsigned want, unsi
     }
 }
 
-// LDS panel (cnt contiguous elements) -> mailbox slot, 16-byte sc1 stores (the caller drains and raises the flag)
-__device__ __forceinline__ void ring_send(const double2* __restrict__ src, double2* slot, int cnt, int tid) {
+// LDS panel (cnt contiguous elements) -> mailbox slot, 16-byte stores (the caller drains and raises the flag): sc1
+// (write-through to memory, any placement) or, when the block's workgroups have FOUND themselves on one XCD (`local`, see
+// ring_run), plain stores that stay in that XCD's L2 -- the reader's sc1 loads are served from the same L2
+__device__ __forceinline__ void ring_send(const double2* __restrict__ src, double2* slot, int cnt, int tid, bool local) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slot, 0, cnt * 16, 0x00020000);
-    for (int idx = tid; idx < cnt; idx += RING_THREADS) {
-        const double2 v = src[idx];
-        ring_u4 u;
-        __builtin_memcpy(&u, &v, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(u, rs, idx * 16, 0, 16);       // aux 16 = sc1
+    if (local) {
+        for (int idx = tid; idx < cnt; idx += RING_THREADS) {
+            const double2 v = src[idx];
+            ring_u4 u;
+            __builtin_memcpy(&u, &v, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, idx * 16, 0, 0);
+        }
+    } else {
+        for (int idx = tid; idx < cnt; idx += RING_THREADS) {
+            const double2 v = src[idx];
+            ring_u4 u;
+            __builtin_memcpy(&u, &v, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs, idx * 16, 0, 16);       // aux 16 = sc1
+        }
     }
+}
+// the epoch word that tells a neighbour its panel has arrived (after the drain and the barrier): agent scope, or -- all
+// workgroups of the block on one XCD -- a store that stays in the shared L2 (the poll is an agent-scope load either way)
+__device__ __forceinline__ void ring_flag(unsigned* flag, unsigned epoch, bool local) {
+    if (local) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // mailbox slot -> LDS panel, every load sc1; all loads of a thread in flight together (cnt <= 9 * 512)
 __device__ __forceinline__ void ring_recv(double2* dst, const double2* slot, int cnt, int tid) {
@@ -1748,6 +1765,7 @@ struct RingArgs {
     double2* mbox;
     unsigned* sync;              // [flags: 2 per workgroup | arrive: nl * max_sweeps | fail | pad | conv (u64): nl * max_sweeps]
     int arrive_off, fail_off, conv_off;      // in 32-bit words (conv_off even)
+    int xcc_off;                 // 32-bit words: one per workgroup, XCD id + 1 once the workgroup has started
     int max_sweeps;
     double tol;
     int* info;
@@ -1756,7 +1774,7 @@ struct RingArgs {
 
 template <int GS, int E>
 __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, const htn_svd_block D, double2* lds, int* s_top, int* s_bot,
-                         unsigned long long* s_rbits, int* s_ok, double* s_bnorm) {
+                         unsigned long long* s_rbits, int* s_ok, double* s_bnorm, int* s_local) {
     constexpr int mp = GS * E;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = it.P, k = it.k, w = it.w, n = it.n, m = D.m;
@@ -1776,8 +1794,31 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
         s_top[tid] = 2 * tid;
         s_bot[tid] = 2 * tid + 1;
     }
-    if (tid == 0) *s_ok = 1;
+    if (tid == 0) {
+        *s_ok = 1;
+        // Which XCD is this?  The host places a block's workgroups at grid positions that the dispatcher has been SEEN to
+        // deal to one XCD (position mod 8); nothing promises that, so every workgroup publishes the XCD id it reads from
+        // the hardware register and the block takes the cheaper hand-off (plain stores kept in the shared L2) only if ALL
+        // of its workgroups report the same id -- otherwise the placement-independent sc1 form, as before.  Every
+        // workgroup of the block reads the same P words, so all take the same decision.
+        int local = 0;
+        if (P > 1 && A.xcc_off >= 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc = (xcc & 0xfu) + 1u;
+            unsigned* xw = A.sync + A.xcc_off + it.g0;
+            __hip_atomic_store(xw + k, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            local = 1;
+            for (int q = 0; q < P && local >= 0; ++q) {
+                if (!ring_wait_ge(xw + q, 1u, fail)) local = -1;
+                else if (__hip_atomic_load(xw + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc) local = local > 0 ? 0 : local;
+            }
+            if (local < 0) *s_ok = 0;
+        }
+        *s_local = local > 0 ? 1 : 0;
+    }
     __syncthreads();
+    const bool local = *s_local != 0;
     {   // resident panels <- X (written by the QR kernel before this launch: plain loads), re-padded from X's leading
         // dimension (the rule of the one-workgroup kernel) to mp rows; rows >= m are zero in both
         const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
@@ -1798,7 +1839,7 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
     const long long prof_t0 = wall_clock64();
 #endif
     int sweeps = 0;
-    bool done = n < 2, ok = true;
+    bool done = n < 2, ok = *s_ok != 0;
     const int rounds = 2 * P - 1;
     while (!done && ok && sweeps < A.max_sweeps) {
         double ratio = 0.0;
@@ -1814,20 +1855,20 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
             if (P < 2) continue;
             // ---- panels move one position: send, drain, raise the flags ----
             double2* box = A.mbox + it.mbox;                    // slot of workgroup kd, role, parity: ((kd * 2 + role) * 2 + par)
-            if (k == 0) ring_send(bufB, box + (int64_t)((1 * 2 + 0) * 2 + par) * slot_elems, nb * mp, tid);            // bottom -> top of 1
+            if (k == 0) ring_send(bufB, box + (int64_t)((1 * 2 + 0) * 2 + par) * slot_elems, nb * mp, tid, local);            // bottom -> top of 1
             else {
-                if (k < P - 1) ring_send(bufT, box + (int64_t)(((k + 1) * 2 + 0) * 2 + par) * slot_elems, nt * mp, tid);   // top -> top of k + 1
-                ring_send(bufB, box + (int64_t)(((k - 1) * 2 + 1) * 2 + par) * slot_elems, nb * mp, tid);                  // bottom -> bottom of k - 1
+                if (k < P - 1) ring_send(bufT, box + (int64_t)(((k + 1) * 2 + 0) * 2 + par) * slot_elems, nt * mp, tid, local);   // top -> top of k + 1
+                ring_send(bufB, box + (int64_t)(((k - 1) * 2 + 1) * 2 + par) * slot_elems, nb * mp, tid, local);                  // bottom -> bottom of k - 1
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             RING_T(p2);
             RING_ACC(1, p1, p2);
             if (tid == 0) {
-                if (k == 0) __hip_atomic_store(flags + (it.g0 + 1) * 2 + 0, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k == 0) ring_flag(flags + (it.g0 + 1) * 2 + 0, epoch, local);
                 else {
-                    if (k < P - 1) __hip_atomic_store(flags + (it.g0 + k + 1) * 2 + 0, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(flags + (it.g0 + k - 1) * 2 + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (k < P - 1) ring_flag(flags + (it.g0 + k + 1) * 2 + 0, epoch, local);
+                    ring_flag(flags + (it.g0 + k - 1) * 2 + 1, epoch, local);
                 }
                 // the panel ids follow the same permutation in every workgroup of the block
                 const int t_last = s_top[P - 1], b0 = s_bot[0];
@@ -1900,7 +1941,7 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
 #ifdef HTN_RING_PROF
     if (tid == 0 && blockIdx.x < 256) {
         prof[6] = wall_clock64() - prof_t0;
-        prof[7] = sweeps * 1000 + P;
+        prof[7] = (local ? 1000000 : 0) + sweeps * 1000 + P;
         for (int q = 0; q < 8; ++q) g_ring_prof[blockIdx.x * 8 + q] = prof[q];
     }
 #endif
@@ -1938,25 +1979,26 @@ __global__ __launch_bounds__(RING_THREADS) void k_jacobi_ring(RingArgs A) {
     extern __shared__ double2 g_lds[];
     __shared__ int s_top[RING_MAX_P], s_bot[RING_MAX_P];
     __shared__ unsigned long long s_rbits;
-    __shared__ int s_ok;
+    __shared__ int s_ok, s_local;
     __shared__ double s_bnorm[2 * (RING_THREADS / 16)];      // tracked squared norms | scales of the bottom panel's columns
     const RingItem it = A.items[blockIdx.x];
+    if (it.P <= 0) return;           // (a gap of the XCD-aware placement: see plan_ring)
     const htn_svd_block D = A.desc[A.large_ids[it.li]];
     const int m = D.m;
     const int gs = ring_gs(m), E = ring_e(m);
 #define RING_CASE(GSV, EV) \
-    case EV: ring_run<GSV, EV>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm); break;
+    case EV: ring_run<GSV, EV>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm, &s_local); break;
     if (gs == 16) {                  // m <= 256
         switch (E) {
             RING_CASE(16, 1) RING_CASE(16, 2) RING_CASE(16, 3) RING_CASE(16, 4) RING_CASE(16, 5) RING_CASE(16, 6) RING_CASE(16, 7)
             RING_CASE(16, 8) RING_CASE(16, 9) RING_CASE(16, 10) RING_CASE(16, 11) RING_CASE(16, 12) RING_CASE(16, 13)
             RING_CASE(16, 14) RING_CASE(16, 15)
-            default: ring_run<16, 16>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm);
+            default: ring_run<16, 16>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm, &s_local);
         }
     } else {                         // 256 < m <= 512: E = 5 .. 8
         switch (E) {
             RING_CASE(64, 5) RING_CASE(64, 6) RING_CASE(64, 7)
-            default: ring_run<64, 8>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm);
+            default: ring_run<64, 8>(A, it, D, g_lds, s_top, s_bot, &s_rbits, &s_ok, s_bnorm, &s_local);
         }
     }
 #undef RING_CASE
@@ -2211,9 +2253,16 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     // Ring path (default): all sweeps of the large blocks in one launch per batch of <= #CU workgroups.  The multi-launch
     // pair-visit path stays for blocks the ring cannot take (more CU slots than the chip has) and behind HTN_SVD_PAIRS=1.
     static const bool force_pairs = htn_env_flag("HTN_SVD_PAIRS");
-    std::vector<RingItem> ring_items;
-    std::vector<std::pair<int, int>> ring_batches;            // (first workgroup, count) of each launch
+    std::vector<RingItem> ring_items;                         // in GRID order of their launch (gaps: P = 0)
+    std::vector<std::pair<int, int>> ring_batches;            // (first item, grid size) of each launch
+    int ring_wgs = 0;                                         // workgroups with work (flag / id words are indexed densely)
     int64_t ring_mbox_elems = 0;
+    // XCD-aware placement: a block's workgroups go to grid positions 8 s + x with ONE x -- the dispatcher has been seen to
+    // deal position p to XCD p mod 8 (tools/gemm_prof.py), so they share an L2 and the kernel, after CHECKING the XCD ids it
+    // reads at run time, hands panels over through that L2.  Speed only: a block whose workgroups find themselves on
+    // different XCDs uses the placement-independent hand-off.  HTN_RING_NO_XCD=1: dense placement, as before.
+    static const bool no_xcd = htn_env_flag("HTN_RING_NO_XCD");
+    const int n_xcd = (!no_xcd && g_js.cu_count > 0 && g_js.cu_count % 8 == 0) ? 8 : 1;
     const int ring_cap = std::max(1, std::min(g_js.cu_count > 0 ? g_js.cu_count : 256, 256));
     // CU slots and panel width of every large block; batches of <= #CU workgroups (all workgroups of a launch must be
     // co-resident: they wait for each other).  false: some block needs more slots than the ring supports.
@@ -2221,6 +2270,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         ring_items.clear();
         ring_batches.clear();
         ring_mbox_elems = 0;
+        ring_wgs = 0;
         struct Blk {
             int li, P, w, mp;
         };
@@ -2240,19 +2290,40 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         std::stable_sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) { return a.P > b.P; });
         std::vector<char> placed(blks.size(), 0);
         size_t left = blks.size();
+        int nx = n_xcd;                                       // (a block with more slots than one XCD has CUs: dense placement)
+        for (const Blk& B : blks)
+            if (B.P > ring_cap / nx) nx = 1;
+        const int lane_cap = ring_cap / nx;                     // CU slots of one XCD (of the chip when nx = 1)
         while (left) {
             const int first = (int)ring_items.size();
-            int used = 0;
+            std::vector<int> lane_used((size_t)nx, 0);
+            struct Put {
+                int q, x, s0;
+            };
+            std::vector<Put> puts;
             for (size_t q = 0; q < blks.size(); ++q) {
-                if (placed[q] || used + blks[q].P > ring_cap) continue;
-                const Blk& B = blks[q];
-                for (int k = 0; k < B.P; ++k) ring_items.push_back({B.li, k, B.P, B.w, n_eff[B.li], first + used, ring_mbox_elems});
-                ring_mbox_elems += (int64_t)B.P * 4 * B.w * B.mp;
-                used += B.P;
+                if (placed[q]) continue;
+                int x = 0;
+                for (int y = 1; y < nx; ++y)
+                    if (lane_used[y] < lane_used[x]) x = y;
+                if (lane_used[x] + blks[q].P > lane_cap) continue;
+                puts.push_back({(int)q, x, lane_used[x]});
+                lane_used[x] += blks[q].P;
                 placed[q] = 1;
                 --left;
             }
-            ring_batches.push_back({first, used});
+            int depth = 0;
+            for (int y = 0; y < nx; ++y) depth = std::max(depth, lane_used[y]);
+            const int grid = depth * nx;
+            ring_items.resize((size_t)first + grid, RingItem{0, 0, 0, 0, 0, 0, 0});
+            for (const Put& pt : puts) {
+                const Blk& B = blks[pt.q];
+                for (int k = 0; k < B.P; ++k)
+                    ring_items[(size_t)first + (size_t)(pt.s0 + k) * nx + pt.x] = {B.li, k, B.P, B.w, n_eff[B.li], ring_wgs, ring_mbox_elems};
+                ring_mbox_elems += (int64_t)B.P * 4 * B.w * B.mp;
+                ring_wgs += B.P;
+            }
+            ring_batches.push_back({first, grid});
         }
         return true;
     };
@@ -2300,11 +2371,12 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         if (!use_ring && upload_rounds()) return 1;
     }
     if (use_ring) {
-        const int n_wg = (int)ring_items.size();
-        // sync block (32-bit words): [flags: 2 per workgroup | arrivals: nl x max_sweeps | failure word | pad] then the
-        // 64-bit maxima, nl x max_sweeps; zeroed as ONE block that starts its allocation and is a multiple of 16 bytes
-        const int arrive_off = 2 * n_wg, fail_off = arrive_off + nl * max_sweeps;
-        const int conv_off = (fail_off + 1 + 3) & ~3;
+        const int n_wg = ring_wgs, n_items = (int)ring_items.size();
+        // sync block (32-bit words): [flags: 2 per workgroup | arrivals: nl x max_sweeps | failure word | XCD ids: 1 per
+        // workgroup | pad] then the 64-bit maxima, nl x max_sweeps; zeroed as ONE block that starts its allocation and is a
+        // multiple of 16 bytes
+        const int arrive_off = 2 * n_wg, fail_off = arrive_off + nl * max_sweeps, xcc_off = fail_off + 1;
+        const int conv_off = (xcc_off + n_wg + 3) & ~3;
         const size_t sync_bytes = ((size_t)conv_off * 4 + (size_t)nl * max_sweeps * 8 + 15) & ~(size_t)15;
         if (sync_bytes > g_js.ring_sync_bytes) {
             if (g_js.ring_sync) HIP_TRY(hipFree(g_js.ring_sync));
@@ -2320,22 +2392,23 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
             g_js.ring_mbox_bytes = mbox_bytes + mbox_bytes / 2;
             if (htn_debug_poison()) HIP_TRY(hipMemset(g_js.ring_mbox, 0xFF, g_js.ring_mbox_bytes));
         }
-        if ((size_t)n_wg > g_js.ring_items_cap) {
+        if ((size_t)n_items > g_js.ring_items_cap) {
             if (g_js.ring_items) HIP_TRY(hipFree(g_js.ring_items));
             if (g_js.ring_items_h) HIP_TRY(hipHostFree(g_js.ring_items_h));
             g_js.ring_items = g_js.ring_items_h = nullptr, g_js.ring_items_cap = 0;
-            HIP_TRY(hipMalloc(&g_js.ring_items, sizeof(RingItem) * 2 * n_wg));
-            HIP_TRY(hipHostMalloc(&g_js.ring_items_h, sizeof(RingItem) * 2 * n_wg, hipHostMallocDefault));
-            g_js.ring_items_cap = 2 * (size_t)n_wg;
+            HIP_TRY(hipMalloc(&g_js.ring_items, sizeof(RingItem) * 2 * n_items));
+            HIP_TRY(hipHostMalloc(&g_js.ring_items_h, sizeof(RingItem) * 2 * n_items, hipHostMallocDefault));
+            g_js.ring_items_cap = 2 * (size_t)n_items;
         }
-        memcpy(g_js.ring_items_h, ring_items.data(), sizeof(RingItem) * n_wg);
+        memcpy(g_js.ring_items_h, ring_items.data(), sizeof(RingItem) * n_items);
         for (int li = 0; li < nl; ++li) h_ring_sw[li] = 0;
-        HIP_TRY(hipMemcpyAsync(g_js.ring_items, g_js.ring_items_h, sizeof(RingItem) * n_wg, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(g_js.ring_items, g_js.ring_items_h, sizeof(RingItem) * n_items, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(g_js.ring_sync, 0, sync_bytes, st));
         RingArgs ra;
         ra.Vj = (double2*)Vj, ra.G = (double2*)G, ra.S = S, ra.desc = desc, ra.large_ids = d_ids;
         ra.perm = d_perm, ra.zero2 = d_zero, ra.mbox = (double2*)g_js.ring_mbox, ra.sync = (unsigned*)g_js.ring_sync;
         ra.arrive_off = arrive_off, ra.fail_off = fail_off, ra.conv_off = conv_off, ra.max_sweeps = max_sweeps, ra.tol = tol;
+        ra.xcc_off = xcc_off;
         ra.info = info_dev, ra.sweeps_out = d_ring_sw;
         for (auto& bt : ring_batches) {
             ra.items = (const RingItem*)g_js.ring_items + bt.first;

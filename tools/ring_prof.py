@@ -31,9 +31,11 @@ for a in sys.argv[1:]:
     out = np.zeros(256 * 8, dtype=np.int64)
     ops.lib.htn_ring_prof_dump(C.c_void_p(out.ctypes.data))
     out = out.reshape(256, 8)
-    P = int(out[0, 7] % 1000)
-    sw = int(out[0, 7] // 1000)
+    rows = [r for r in range(256) if out[r, 6] > 0]          # (grid positions with work: the XCD-aware placement leaves gaps)
+    P = int(out[rows[0], 7] % 1000)
+    sw = int(out[rows[0], 7] // 1000 % 1000)
+    local = int(out[rows[0], 7] // 1000000)
     names = ["cross", "send+drain", "flags+wait", "recv", "intra", "conv", "total"]
-    print(f"{a}: P={P} sweeps={sw}  (us per sweep, per workgroup; 100 MHz ticks)")
-    for k in range(P):
-        print("  k=%2d " % k + "  ".join(f"{n} {out[k, q] / 100.0 / max(sw, 1):7.1f}" for q, n in enumerate(names)))
+    print(f"{a}: P={P} sweeps={sw} hand-off through one XCD's L2: {bool(local)}  grid positions {rows[:P]}  (us per sweep, per workgroup; 100 MHz ticks)")
+    for k, r in enumerate(rows[:P]):
+        print("  k=%2d " % k + "  ".join(f"{n} {out[r, q] / 100.0 / max(sw, 1):7.1f}" for q, n in enumerate(names)))
