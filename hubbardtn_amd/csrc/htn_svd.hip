@@ -432,6 +432,7 @@ __device__ __forceinline__ void lds_barrier() {
 typedef unsigned int qr_u4 __attribute__((ext_vector_type(4)));
 struct QrShare {
     int NW, role;
+    bool local;              // every workgroup of the block reports the same XCD: bulk stores stay in that XCD's L2 (plain), see k_qr_large
     double2* qn;             // [16 * ldq] panel basis (global copy)
     int* scol;               // [n0] logical -> physical column
     double* cn2;             // [n0] squared norms the helpers computed (by logical position)
@@ -463,14 +464,15 @@ __device__ __forceinline__ double2 qr_ld(const double2* base, __amdgpu_buffer_rs
     return v;
 }
 template <bool SH>
-__device__ __forceinline__ void qr_st(double2* base, __amdgpu_buffer_rsrc_t rs, int idx, double2 v) {
+__device__ __forceinline__ void qr_st(double2* base, __amdgpu_buffer_rsrc_t rs, int idx, double2 v, bool local) {
     if (!SH) {
         base[idx] = v;
         return;
     }
     qr_u4 u;
     __builtin_memcpy(&u, &v, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(u, rs, idx * 16, 0, 16);
+    if (local) __builtin_amdgcn_raw_buffer_store_b128(u, rs, idx * 16, 0, 0);      // stays in the XCD's L2; the readers' sc1 loads hit it there
+    else __builtin_amdgcn_raw_buffer_store_b128(u, rs, idx * 16, 0, 16);
 }
 
 // one 16-column chunk of the trailing update by one wave: rows j0 .. of R for its columns (-> X), then the columns themselves
@@ -479,7 +481,7 @@ template <bool SH>
 __device__ __forceinline__ void qr_trailing_chunk(double2* __restrict__ g0, __amdgpu_buffer_rsrc_t rg, double2* __restrict__ Xg,
                                                   __amdgpu_buffer_rsrc_t rx, const double2* Qn, int ldq, const int* s_col, int m0,
                                                   int m0p, int n0, int mp, int j0, int nb_eff, int k_first, int ch, bool last_panel,
-                                                  double* norm_out, bool norm_shared, int lane) {
+                                                  double* norm_out, bool norm_shared, int lane, bool local) {
     const int l15 = lane & 15, l4 = lane >> 4;
     const int nks = m0p >> 2;
     const int k = k_first + 16 * ch + l15;
@@ -514,7 +516,7 @@ __device__ __forceinline__ void qr_trailing_chunk(double2* __restrict__ g0, __am
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int t = l4 + 4 * reg;
-        if (valid && t < nb_eff) qr_st<SH>(Xg, rx, (j0 + t) * mp + pk, make_double2(cr[reg], -ci[reg]));
+        if (valid && t < nb_eff) qr_st<SH>(Xg, rx, (j0 + t) * mp + pk, make_double2(cr[reg], -ci[reg]), local);
     }
     if (last_panel) return;                       // no later panel reads the trailing columns
     double nrm = 0.0;
@@ -539,7 +541,7 @@ __device__ __forceinline__ void qr_trailing_chunk(double2* __restrict__ g0, __am
             const int i = i0 + l4 + 4 * reg;
             if (valid && i < m0) {
                 const double2 x = make_double2(old[reg].x - dr[reg], old[reg].y - di[reg]);
-                qr_st<SH>(g0, rg, abase + i, x);
+                qr_st<SH>(g0, rg, abase + i, x, local);
                 nrm += x.x * x.x + x.y * x.y;
             }
         }
@@ -577,7 +579,7 @@ __device__ __forceinline__ void qr_helper(double2* __restrict__ g0, int m0, int 
         const int nchunks = (n0 - k_first + 15) >> 4;
         for (int q = wave; sh.role + sh.NW * q < nchunks; q += JAC_THREADS / 64)
             qr_trailing_chunk<true>(g0, rg, Xg, rx, Qn, ldq, s_col, m0, m0p, n0, mp, j0, nb_eff, k_first, sh.role + sh.NW * q, last_panel,
-                                    sh.cn2, true, lane);
+                                    sh.cn2, true, lane, sh.local);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store(sh.hflag + sh.role, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -613,7 +615,7 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
     __shared__ int s_nb;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int m0p = (m0 + 15) & ~15, ldq = m0p + 1;
-    for (int idx = tid; idx < mp * r; idx += JAC_THREADS) qr_st<SH>(Xg, rx, idx, make_double2(0.0, 0.0));
+    for (int idx = tid; idx < mp * r; idx += JAC_THREADS) qr_st<SH>(Xg, rx, idx, make_double2(0.0, 0.0), sh.local);
     for (int k = wave; k < n0; k += JAC_THREADS / 64) {
         double c = 0.0;
         for (int i = lane; i < m0; i += 64) {
@@ -804,7 +806,7 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
         }
         if (tid < nb_eff) s_col[j0 + tid] = s_pos[tid];
         if (tid < 256 && (tid >> 4) < nb_eff && (tid & 15) < nb)      // rows of R before a column's own pivot step: 0
-            qr_st<SH>(Xg, rx, (j0 + (tid >> 4)) * mp + s_pc[tid & 15], s_r[tid >> 4][tid & 15]);
+            qr_st<SH>(Xg, rx, (j0 + (tid >> 4)) * mp + s_pc[tid & 15], s_r[tid >> 4][tid & 15], sh.local);
         __syncthreads();
         QR_T(q4);
         QR_ACC(3, q3, q4);
@@ -816,7 +818,7 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
         if (SH && nchunks > 0) {
             // publish the panel: basis, column map of the trailing part, geometry; drain; ONE lane raises the epoch
             const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)sh.qn, 0, 16 * ldq * 16, 0x00020000);
-            for (int idx = tid; idx < 16 * ldq; idx += JAC_THREADS) qr_st<true>(sh.qn, rq, idx, Qn[idx]);
+            for (int idx = tid; idx < 16 * ldq; idx += JAC_THREADS) qr_st<true>(sh.qn, rq, idx, Qn[idx], sh.local);
             for (int k = k_first + tid; k < n0; k += JAC_THREADS) __hip_atomic_store(sh.scol + k, s_col[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tid == 0) {
                 __hip_atomic_store(sh.meta + 0, j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -831,7 +833,7 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
             if (tid == 0) __hip_atomic_store(sh.qflag, pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         for (int q = wave; NW * q < nchunks; q += JAC_THREADS / 64)            // the master's share: chunks ch with ch % NW == 0
-            qr_trailing_chunk<SH>(g0, rg, Xg, rx, Qn, ldq, s_col, m0, m0p, n0, mp, j0, nb_eff, k_first, NW * q, last_panel, s_cn2, false, lane);
+            qr_trailing_chunk<SH>(g0, rg, Xg, rx, Qn, ldq, s_col, m0, m0p, n0, mp, j0, nb_eff, k_first, NW * q, last_panel, s_cn2, false, lane, sh.local);
         if (SH && nchunks > 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's own column updates are out before the next panel reads them
             __syncthreads();
@@ -880,18 +882,24 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
 
 // one workgroup per LARGE block (X = R^H does not fit the LDS window): pivoted QR only; the sweeps follow as
 // multi-launch block Jacobi.  Runs beside k_jacobi_svd (small blocks) on a forked stream.
+#define QR_SYNC_WORDS 16         // per large block: panel epoch | helper epochs [1 .. 4] | ... | XCD ids [8 .. 11]
 #define QR_BOX_BYTES 137728      // per large block: 16 x 513 complex128 (Q_p) | 512 int (column map) | 512 double (norms) | meta
 __global__ __launch_bounds__(JAC_THREADS) void k_qr_large(double2* __restrict__ G, double2* __restrict__ Vj,
                                                           const htn_svd_block* __restrict__ desc,
                                                           const int* __restrict__ large_ids, int* __restrict__ perm,
                                                           double* __restrict__ zero2_out, double cut2,
                                                           int* __restrict__ rank_host, int NW, char* __restrict__ qr_box,
-                                                          unsigned* __restrict__ qr_sync, int nl) {
+                                                          unsigned* __restrict__ qr_sync, int nl, int nx) {
     extern __shared__ double2 g_lds[];
     __shared__ double s_piv[2];
     __shared__ int s_col[64 * JAC_MAXEL];
     __shared__ double s_cn2[64 * JAC_MAXEL];
-    const int li = blockIdx.x / NW, role = blockIdx.x % NW;
+    __shared__ int s_qlocal;
+    // grid position -> (block, role): with helpers (NW > 1) the workgroups of one block sit at positions p = nx s + x with ONE x
+    // (nx = 8: the dispatcher has been seen to deal position p to XCD p mod 8), blocks x, x + nx, ... stacked along s
+    const int px = (int)(blockIdx.x % (unsigned)nx), ps = (int)(blockIdx.x / (unsigned)nx);
+    const int li = (ps / NW) * nx + px, role = ps % NW;
+    if (li >= nl) return;             // (a gap of the placement)
     const htn_svd_block D = desc[large_ids[li]];
     const int m = D.m, n = D.n, m0 = D.pad, tid = threadIdx.x;
     const int gsx = m <= 16 * JAC_MAXEL ? 16 : (m <= 32 * JAC_MAXEL ? 32 : 64);
@@ -904,9 +912,30 @@ __global__ __launch_bounds__(JAC_THREADS) void k_qr_large(double2* __restrict__ 
     sh.scol = (int*)(box + 16 * 513 * 16);
     sh.cn2 = (double*)(box + 16 * 513 * 16 + 512 * 4);
     sh.meta = (int*)(box + 16 * 513 * 16 + 512 * 4 + 512 * 8);
-    sh.qflag = qr_sync + li * 8;
-    sh.hflag = qr_sync + li * 8 + 1;
-    sh.fail = qr_sync + nl * 8;
+    sh.qflag = qr_sync + li * QR_SYNC_WORDS;
+    sh.hflag = qr_sync + li * QR_SYNC_WORDS + 1;
+    sh.fail = qr_sync + nl * QR_SYNC_WORDS;
+    sh.local = false;
+    if (NW > 1) {
+        // the same check as in the ring kernel (ring_run): take the hand-off through the XCD's L2 only if every workgroup of the
+        // block READS the same XCD id from the hardware; any other outcome keeps the placement-independent sc1 form
+        if (tid == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc = (xcc & 0xfu) + 1u;
+            unsigned* xw = qr_sync + li * QR_SYNC_WORDS + 8;
+            __hip_atomic_store(xw + role, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int local = 1;
+            for (int q = 0; q < NW && local >= 0; ++q) {
+                if (!qr_wait_ge(xw + q, 1u, sh.fail)) local = -1;
+                else if (__hip_atomic_load(xw + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc) local = 0;
+            }
+            s_qlocal = local;
+        }
+        __syncthreads();
+        sh.local = s_qlocal > 0;
+        // (a timed-out wait has raised the failure word: the master's and the helpers' first hand-off see it and give up)
+    }
     if (role > 0) {
         qr_helper(G + D.g_off, m0, m, n, X, mp, s_col, (double2*)g_lds, tid, sh);
         return;
@@ -1970,7 +1999,7 @@ __device__ __forceinline__ void ring_run(const RingArgs A, const RingItem it, co
     }
     if (k == 0 && tid == 0) {
         A.info[A.large_ids[it.li]] = (done && ok) ? sweeps : -(sweeps > 0 ? sweeps : 1);
-        A.sweeps_out[it.li] = ok ? sweeps : 0;
+        A.sweeps_out[it.li] = ok ? sweeps + ((local || P == 1) ? 1000 : 0) : 0;      // (+ 1000: hand-offs went through one XCD's L2)
         __threadfence_system();
     }
 }
@@ -2025,6 +2054,7 @@ struct JacScratch {
     void* ring_items_h = nullptr;
     size_t ring_items_cap = 0;
     int cu_count = 0;
+    int xcd_local = 0;                  // 1: in the last ring launch every block's workgroups found themselves on one XCD
     hipStream_t aux = nullptr;          // forked stream: small blocks run beside the large-block pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sweep[2] = {nullptr, nullptr};
     ~JacScratch() {
@@ -2196,8 +2226,8 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     const size_t off_ids = 0, off_slot = off_ids + sizeof(int) * nl, off_perm = off_slot + sizeof(int) * n_blocks;
     const size_t off_zero = off_perm + sizeof(int) * nl * 64 * JAC_MAXEL;
     const size_t off_ratio = (off_zero + sizeof(double) * nl + 7) / 8 * 8, off_done = off_ratio + 8 * nl;
-    const size_t off_sw = off_done + sizeof(int) * nl, off_qsync = off_sw + sizeof(int) * nl;      // qsync: 8 words per block + failure word
-    const size_t off_items = (off_qsync + sizeof(unsigned) * (8 * (size_t)nl + 8) + 31) / 32 * 32;
+    const size_t off_sw = off_done + sizeof(int) * nl, off_qsync = off_sw + sizeof(int) * nl;      // qsync: QR_SYNC_WORDS per block + failure word
+    const size_t off_items = (off_qsync + sizeof(unsigned) * (QR_SYNC_WORDS * (size_t)nl + 8) + 31) / 32 * 32;
     const size_t dev_bytes = off_items + sizeof(JacPairItem) * n_items_max;
     JacScratch* jsp = nullptr;
     if (js_get(st, &jsp)) return 1;
@@ -2234,7 +2264,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     // every small copy / fill is a separate blit launch on the stream: they are enqueued BEFORE the QR (nothing here
     // depends on it unless a rank cut sizes the tournament), merged where the regions are contiguous
     HIP_TRY(hipMemcpyAsync(d_ids, h_ids, sizeof(int) * (nl + n_blocks), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(d_ratio, 0, 16 * (size_t)nl + sizeof(unsigned) * (8 * (size_t)nl + 8), st));      // ratio (8 nl) | done (4 nl) | sweeps (4 nl) | qsync
+    HIP_TRY(hipMemsetAsync(d_ratio, 0, 16 * (size_t)nl + sizeof(unsigned) * (QR_SYNC_WORDS * (size_t)nl + 8), st));      // ratio (8 nl) | done (4 nl) | sweeps (4 nl) | qsync
     const double cut2 = g_jac_cut * g_jac_cut;
     std::vector<int> n_eff(nl);
     for (int li = 0; li < nl; ++li) n_eff[li] = desc_host[large[li]].n;
@@ -2345,11 +2375,21 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         int max_n0 = 0;
         for (int li = 0; li < nl; ++li) max_n0 = std::max(max_n0, (int)desc_host[large[li]].m);
         static const bool qr_single = htn_env_flag("HTN_QR_SINGLE");
-        // Measured (tools/ring_prof.py, HTN_QR_PROF): every shared byte goes to memory and comes back from memory (sc1), so a
-        // chunk's operand loads wait ~2 us each instead of an L2 hit: 202 x 202 blocks LOSE (trailing 483 -> 655 us with four
-        // workgroups), 400 x 400 blocks gain (3.0 -> 2.3 ms).  Helpers only where the trailing update dominates by far.
-        int NW = (qr_single || max_n0 <= 288) ? 1 : 4;
-        NW = std::max(1, std::min(NW, std::max(1, std::min(g_js.cu_count > 0 ? g_js.cu_count : 256, 256)) / std::max(nl, 1)));
+        // Measured (tools/ring_prof.py, HTN_QR_PROF): in the placement-independent form every shared byte goes to memory and
+        // comes back from memory (sc1), so a chunk's operand loads wait ~2 us each instead of an L2 hit: 202 x 202 blocks LOSE
+        // (trailing 483 -> 655 us with four workgroups), 400 x 400 blocks gain (3.0 -> 2.3 ms).
+        static const int env_nw = getenv("HTN_QR_NW") ? atoi(getenv("HTN_QR_NW")) : 0;      // (experiments: helpers at any size)
+        // Helpers: above 288 columns always (the trailing update dominates by far: 400 x 400 3.9 -> 2.5 ms); below, only while the
+        // kernels keep finding a block's workgroups on one XCD (202 x 202: 884 -> 764 us through the shared L2, but 964 us when
+        // every shared byte has to go through memory).
+        int NW = qr_single ? 1 : ((max_n0 > 288 || g_js.xcd_local) ? 4 : 1);
+        if (env_nw > 0 && !qr_single) NW = std::min(env_nw, 4);
+        // placement: the workgroups of a block at grid positions of one residue mod 8 (see k_qr_large); the gaps count
+        // against the co-residency bound like everything else
+        const int cus = std::max(1, std::min(g_js.cu_count > 0 ? g_js.cu_count : 256, 256));
+        const int qnx = (NW > 1 && n_xcd > 1) ? n_xcd : 1;
+        const int nl_pad = (nl + qnx - 1) / qnx * qnx;
+        NW = std::max(1, std::min(NW, cus / std::max(nl_pad, 1)));
         if (NW > 1) {
             const size_t need = (size_t)nl * QR_BOX_BYTES;
             if (need > g_js.qr_box_bytes) {
@@ -2360,8 +2400,9 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
                 if (htn_debug_poison()) HIP_TRY(hipMemset(g_js.qr_box, 0xFF, need * 2));
             }
         }
-        hipLaunchKernelGGL(k_qr_large, dim3(nl * NW), dim3(JAC_THREADS), qr_lds, st, (double2*)G, (double2*)Vj, desc, d_ids,
-                           d_perm, d_zero, cut2, d_rank, NW, (char*)g_js.qr_box, d_qsync, nl);
+        const int qgrid_nx = NW > 1 ? qnx : 1;
+        hipLaunchKernelGGL(k_qr_large, dim3((NW > 1 ? nl_pad : nl) * NW), dim3(JAC_THREADS), qr_lds, st, (double2*)G, (double2*)Vj, desc, d_ids,
+                           d_perm, d_zero, cut2, d_rank, NW, (char*)g_js.qr_box, d_qsync, nl, qgrid_nx);
     }
     if (cut2 > 0.0) {        // the tournament is sized by the ranks the QR found: wait for them (one sync per call)
         HIP_TRY(hipEventRecord(g_js.ev_sweep[0], st));
@@ -2421,7 +2462,14 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         for (int li = 0; li < nl; ++li) {
             if (h_rank[li] < 0) return fail_msg("htn_jacobi_svd_z: a hand-off of the multi-workgroup QR timed out");
             if (h_ring_sw[li] <= 0 && n_eff[li] >= 2) return fail_msg("htn_jacobi_svd_z: a hand-off of the ring Jacobi kernel timed out");
-            used = std::max(used, (int)h_ring_sw[li]);
+            used = std::max(used, (int)h_ring_sw[li] % 1000);
+        }
+        {   // what the kernel saw of the placement steers the NEXT call's choice of QR helpers (below 288 columns they only pay
+            // when the block's workgroups share an L2)
+            int all_local = n_xcd > 1 ? 1 : 0;
+            for (int li = 0; li < nl; ++li)
+                if (n_eff[li] >= 2 && h_ring_sw[li] < 1000) all_local = 0;
+            g_js.xcd_local = all_local;
         }
         if (opts && opts->sweeps_used) *opts->sweeps_used = used;
         return 0;
