@@ -6,7 +6,9 @@
   HTN_DEBUG_EVENT_WAITS=1  the Lanczos driver waits for a completed HIP event per step instead of polling the
                            host-mapped step record; the record must still validate.
 
-(A third child runs the fallback SVD path of the large blocks, HTN_SVD_PAIRS=1, against the default ring kernel.)
+(A third child runs the fallback SVD path of the large blocks, HTN_SVD_PAIRS=1, against the default ring kernel; a fourth,
+HTN_RING_NO_XCD=1, the dense workgroup placement in which the large-block kernels hand panels over through memory instead
+of one XCD's L2 -- the same arithmetic, so again bit for bit.)
 Both are read once per process, so each case runs `python tests/test_debug_gpu.py` as ONE child process (one extra GPU
 process at a time) and must reproduce the in-process run of the same schedule BIT FOR BIT: energies after every sweep
 and the centre Schmidt spectrum.  The schedule covers the one-workgroup SVD, the forced large-block SVD path
@@ -114,6 +116,13 @@ def test_pair_visit_svd_path_agrees_with_the_ring_path(baseline):
             a = np.array([float.fromhex(x) for x in va])
             b = np.array([float.fromhex(x) for x in other[name]["spec"][c]])
             assert a.shape == b.shape and np.abs(a - b).max() <= 1e-9 * a.max(), (name, c)
+
+
+def test_dense_placement_changes_nothing(baseline):
+    """HTN_RING_NO_XCD=1: the workgroups of a large block are NOT steered to one XCD, so k_jacobi_ring / k_qr_large use the
+    placement-independent hand-off (write-through stores) instead of the one through the shared L2 -- which bytes travel how
+    must not change a single bit of the result"""
+    _same(baseline, _child("HTN_RING_NO_XCD"))
 
 
 def test_event_waits_change_nothing(baseline):
