@@ -1621,14 +1621,22 @@ __device__ __forceinline__ double ring_rotate(double2 (&a)[E], const double2 (&b
 template <int GS, int E>
 __device__ __forceinline__ double ring_rotate_scaled(double2 (&a)[E], const double2 (&b)[E], double2* b_out, double& aa, double& bb,
                                                      double& sa, double& sb, double tol2, double zero2) {
-    double gr = 0.0, gi = 0.0;
+    // conj(a_st) * b_st in FOUR independent chains (even / odd elements x re / im): a dependent f64 multiply-add cannot issue
+    // back to back, and with one busy wave per SIMD nothing else fills the slots
+    double gr = 0.0, gi = 0.0, gr1 = 0.0, gi1 = 0.0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        gr = fma(a[e].x, b[e].x, fma(a[e].y, b[e].y, gr));      // conj(a_st) * b_st
+    for (int e = 0; e + 1 < E; e += 2) {
+        gr = fma(a[e].x, b[e].x, fma(a[e].y, b[e].y, gr));
         gi = fma(a[e].x, b[e].y, fma(-a[e].y, b[e].x, gi));
+        gr1 = fma(a[e + 1].x, b[e + 1].x, fma(a[e + 1].y, b[e + 1].y, gr1));
+        gi1 = fma(a[e + 1].x, b[e + 1].y, fma(-a[e + 1].y, b[e + 1].x, gi1));
     }
-    gr = group_sum<GS>(gr);
-    gi = group_sum<GS>(gi);
+    if (E & 1) {
+        gr = fma(a[E - 1].x, b[E - 1].x, fma(a[E - 1].y, b[E - 1].y, gr));
+        gi = fma(a[E - 1].x, b[E - 1].y, fma(-a[E - 1].y, b[E - 1].x, gi));
+    }
+    gr = group_sum<GS>(gr + gr1);
+    gi = group_sum<GS>(gi + gi1);
     if (aa <= zero2 || bb <= zero2) return 0.0;
     const double ss = sa * sb;
     const double g2 = ss * ss * fma(gr, gr, gi * gi);           // |g|^2 of the true columns
