@@ -421,14 +421,19 @@ __device__ __forceinline__ void lds_barrier() {
 // ---- trailing update shared between workgroups ----------------------------------------------------------------------
 // The trailing update of a panel (C = Q_p^H A, A <- A - Q_p C on the MFMA pipe) is 55 % of k_qr_large on a 202 x 202 block and
 // runs at the MFMA rate of ONE CU (measured 471 of 860 us; window 81, panel steps 299), 77 % on a 400 x 400 block (3.0 of
-// 3.9 ms).  With NW > 1 workgroups per block (used above 288 columns, see the launch site) the
-// master (role 0) keeps the pivoting and the panel factorisation and publishes, per panel, the panel basis Q_p, the column
-// map and the panel's geometry; every workgroup then updates the 16-column chunks ch with ch % NW == role and the helpers
-// hand back the new column norms.  Everything that crosses workgroups inside the launch follows cdna_hip_programming.md
-// section 6, Guideline 16 (first table row of MI355X_MICROARCH.md "visibility"): every store of shared bytes -- Q_p, the
-// map, the updated columns of A, the rows of R in X, the norms -- is a write-through (sc1) store, every storing wave drains,
-// workgroup barrier, ONE lane raises an epoch with an agent-scope atomic store; the other side polls that word from one lane,
-// workgroup barrier, and every load of shared bytes is an sc1 load.  No placement assumption; polls are bounded (ring_wait_ge).
+// 3.9 ms).  With NW > 1 workgroups per block (see the launch site for when) the master (role 0) keeps the pivoting and the
+// panel factorisation and publishes, per panel, the panel basis Q_p, the column map and the panel's geometry; every workgroup
+// then updates the 16-column chunks ch with ch % NW == role -- all its waves together, qr_trailing_coop -- and the helpers hand
+// back the new column norms.  Everything that crosses workgroups inside the launch follows cdna_hip_programming.md section 6,
+// Guideline 16 (first table row of MI355X_MICROARCH.md "visibility"): every storing wave drains, workgroup barrier, ONE lane
+// raises an epoch with an agent-scope atomic store; the other side polls that word from one lane, workgroup barrier, and every
+// load of shared bytes is an sc1 load (served by the L2).  The STORES of the shared bytes -- Q_p, the updated columns of A, the
+// rows of R in X -- come in two flavours: write-through (sc1), correct wherever the workgroups run; or plain, kept in the
+// XCD's L2, used only when every workgroup of the block has read the same XCD id from the hardware (k_qr_large) -- the
+// launch puts a block's workgroups at grid positions of one residue mod 8, which the dispatcher has been seen to deal to one
+// XCD, but nothing is assumed: a block that finds itself spread out takes the first flavour.  Polls are bounded (qr_wait_ge).
+// Measured, 202 x 202 (tools/ring_prof.py, -DHTN_QR_PROF): one workgroup 858 us (trailing 452); four workgroups through
+// memory 964; four through the shared L2 755; the same with all 16 waves of a workgroup on its chunks 619 (trailing 212).
 typedef unsigned int qr_u4 __attribute__((ext_vector_type(4)));
 struct QrShare {
     int NW, role;
@@ -555,8 +560,144 @@ __device__ __forceinline__ void qr_trailing_chunk(double2* __restrict__ g0, __am
 }
 
 // a helper workgroup of a block: per published panel, fetch Q_p and the column map, update its chunks, report
+// The trailing update of one workgroup's chunks (ch = role, role + NW, ... < nchunks) by ALL its 16 waves.  One wave per chunk
+// (qr_trailing_chunk) leaves most of the SIMDs idle once helpers share the chunks: four workgroups x three chunks = three
+// busy waves per CU for 12 us (404 f64 MFMAs at 64 clk).  Here S = 4 waves share a chunk when the block is small enough for
+// the partial sums to fit the LDS beside the panel (m0p <= 256; `part` != nullptr): part p of a chunk takes every S-th group
+// of four k-steps of C = Q_p^H A -- the S partial C tiles are added through LDS in part order, every part ends up with the
+// same full C in the MFMA's D layout -- and every S-th row tile of A <- A - Q_p C; part 0 writes the rows of R, the column
+// norms are added through LDS in part order.  S depends on the block's size only, never on NW or on which workgroup has the
+// chunk: the result is the same bit for bit with or without helpers.  Called by every wave of the workgroup (barriers).
+template <bool SH>
+__device__ __forceinline__ void qr_trailing_coop(double2* __restrict__ g0, __amdgpu_buffer_rsrc_t rg, double2* __restrict__ Xg,
+                                                 __amdgpu_buffer_rsrc_t rx, const double2* Qn, int ldq, const int* s_col, int m0,
+                                                 int m0p, int n0, int mp, int j0, int nb_eff, int k_first, int nchunks, int role,
+                                                 int NW, bool last_panel, double* norm_out, bool norm_shared, double* part,
+                                                 int tid, bool local) {
+    __shared__ double s_np[JAC_THREADS / 64][16];
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int cnt = nchunks > role ? (nchunks - role + NW - 1) / NW : 0;
+    if (part == nullptr) {             // one wave per chunk
+        for (int q = wave; q < cnt; q += JAC_THREADS / 64)
+            qr_trailing_chunk<SH>(g0, rg, Xg, rx, Qn, ldq, s_col, m0, m0p, n0, mp, j0, nb_eff, k_first, role + NW * q, last_panel, norm_out,
+                                  norm_shared, lane, local);
+        return;
+    }
+    constexpr int S = 4, CPR = (JAC_THREADS / 64) / S;      // waves per chunk, chunks per round
+    const int nks = m0p >> 2;
+    for (int r0 = 0; r0 < cnt; r0 += CPR) {                 // (uniform over the workgroup)
+        const int ci_ = r0 + wave / S, pp = wave % S;
+        const bool act = ci_ < cnt;
+        const int ch = role + NW * ci_;
+        const int k = k_first + 16 * ch + l15;
+        const bool valid = act && k < n0;
+        const int pk = valid ? s_col[k] : 0;
+        const int abase = pk * m0;
+        d4 cr = {0.0, 0.0, 0.0, 0.0}, ci = {0.0, 0.0, 0.0, 0.0};
+        if (act) {
+            const double2* qrow = Qn + l15 * ldq + l4;
+            double2 ring[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ks = 4 * pp + u, i = 4 * ks + l4;
+                ring[u] = (valid && ks < nks && i < m0) ? qr_ld<SH>(g0, rg, abase + i) : make_double2(0.0, 0.0);
+            }
+            for (int ks0 = 4 * pp; ks0 < nks; ks0 += 4 * S) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ks = ks0 + u;
+                    if (ks < nks) {
+                        const double2 b = ring[u];
+                        const int ksn = ks + 4 * S, inx = 4 * ksn + l4;
+                        ring[u] = (valid && ksn < nks && inx < m0) ? qr_ld<SH>(g0, rg, abase + inx) : make_double2(0.0, 0.0);
+                        const double2 qv = qrow[4 * ks];
+                        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.x, b.x, cr, 0, 0, 0);
+                        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.x, b.y, ci, 0, 0, 0);
+                        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(qv.y, b.y, cr, 0, 0, 0);
+                        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-qv.y, b.x, ci, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // partial C tiles -> LDS ([wave][reg][lane]: conflict-free), added in part order by every part
+        {
+            double* mine = part + (size_t)wave * 512 + lane;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                mine[64 * reg] = cr[reg];
+                mine[64 * (4 + reg)] = ci[reg];
+            }
+        }
+        __syncthreads();
+        {
+            const double* base = part + (size_t)(wave - pp) * 512 + lane;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int q = 0; q < S; ++q) {
+                    a += base[q * 512 + 64 * reg];
+                    b += base[q * 512 + 64 * (4 + reg)];
+                }
+                cr[reg] = a;
+                ci[reg] = b;
+            }
+        }
+        if (pp == 0) {                                  // rows j0 + (l4 + 4 reg) of R, column k
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int t = l4 + 4 * reg;
+                if (valid && t < nb_eff) qr_st<SH>(Xg, rx, (j0 + t) * mp + pk, make_double2(cr[reg], -ci[reg]), local);
+            }
+        }
+        if (!last_panel) {                              // (uniform) no later panel reads the trailing columns otherwise
+            double nrm = 0.0;
+            if (act) {
+                for (int i0 = 16 * pp; i0 < m0p; i0 += 16 * S) {
+                    double2 old[4];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int i = i0 + l4 + 4 * reg;
+                        old[reg] = (valid && i < m0) ? qr_ld<SH>(g0, rg, abase + i) : make_double2(0.0, 0.0);
+                    }
+                    d4 dr = {0.0, 0.0, 0.0, 0.0}, di = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double2 qa = Qn[(l4 + 4 * kk) * ldq + i0 + l15];
+                        dr = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.x, cr[kk], dr, 0, 0, 0);
+                        di = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.x, ci[kk], di, 0, 0, 0);
+                        dr = __builtin_amdgcn_mfma_f64_16x16x4f64(-qa.y, ci[kk], dr, 0, 0, 0);
+                        di = __builtin_amdgcn_mfma_f64_16x16x4f64(qa.y, cr[kk], di, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int i = i0 + l4 + 4 * reg;
+                        if (valid && i < m0) {
+                            const double2 x = make_double2(old[reg].x - dr[reg], old[reg].y - di[reg]);
+                            qr_st<SH>(g0, rg, abase + i, x, local);
+                            nrm += x.x * x.x + x.y * x.y;
+                        }
+                    }
+                }
+            }
+            nrm += __shfl_xor(nrm, 16, 64);      // over the 4 lanes (l4) that share a column
+            nrm += __shfl_xor(nrm, 32, 64);
+            if (l4 == 0) s_np[wave][l15] = nrm;
+            __syncthreads();
+            if (valid && pp == 0 && l4 == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < S; ++q) t += s_np[wave + q][l15];
+                if (norm_shared) __hip_atomic_store(norm_out + k, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else norm_out[k] = t;
+            }
+        }
+        __syncthreads();                                // the partial tiles and norms are free for the next round
+    }
+}
+
 __device__ __forceinline__ void qr_helper(double2* __restrict__ g0, int m0, int n0, int r, double2* __restrict__ Xg, int mp, int* s_col,
-                                          double2* Qn, int tid, const QrShare sh) {
+                                          double2* Qn, int tid, const QrShare sh, double* part) {
     __shared__ int s_meta[8];
     const int lane = tid & 63, wave = tid >> 6;
     const int m0p = (m0 + 15) & ~15, ldq = m0p + 1;
@@ -577,9 +718,8 @@ __device__ __forceinline__ void qr_helper(double2* __restrict__ g0, int m0, int 
         for (int k = k_first + tid; k < n0; k += JAC_THREADS) s_col[k] = __hip_atomic_load(sh.scol + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const int nchunks = (n0 - k_first + 15) >> 4;
-        for (int q = wave; sh.role + sh.NW * q < nchunks; q += JAC_THREADS / 64)
-            qr_trailing_chunk<true>(g0, rg, Xg, rx, Qn, ldq, s_col, m0, m0p, n0, mp, j0, nb_eff, k_first, sh.role + sh.NW * q, last_panel,
-                                    sh.cn2, true, lane, sh.local);
+        qr_trailing_coop<true>(g0, rg, Xg, rx, Qn, ldq, s_col, m0, m0p, n0, mp, j0, nb_eff, k_first, nchunks, sh.role, sh.NW, last_panel, sh.cn2,
+                               true, part, tid, sh.local);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store(sh.hflag + sh.role, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -602,7 +742,7 @@ extern "C" int htn_qr_prof_dump(long long* out) {
 template <int EL, bool SH>
 __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, int n0, int r,
                                             double2* __restrict__ Xg, int mp, int* s_col, double* s_cn2,
-                                            double* s_piv, double2* Qn, int tid, double cut2, const QrShare sh) {
+                                            double* s_piv, double2* Qn, int tid, double cut2, const QrShare sh, double* part) {
     __shared__ double s_pn[16];
     __shared__ int s_share_ok;
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)g0, 0, m0 * n0 * 16, 0x00020000);
@@ -832,8 +972,9 @@ __device__ __forceinline__ int qrcp_blocked(double2* __restrict__ g0, int m0, in
             ++pub_epoch;
             if (tid == 0) __hip_atomic_store(sh.qflag, pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        for (int q = wave; NW * q < nchunks; q += JAC_THREADS / 64)            // the master's share: chunks ch with ch % NW == 0
-            qr_trailing_chunk<SH>(g0, rg, Xg, rx, Qn, ldq, s_col, m0, m0p, n0, mp, j0, nb_eff, k_first, NW * q, last_panel, s_cn2, false, lane, sh.local);
+        // the master's share: chunks ch with ch % NW == 0
+        qr_trailing_coop<SH>(g0, rg, Xg, rx, Qn, ldq, s_col, m0, m0p, n0, mp, j0, nb_eff, k_first, nchunks, 0, NW, last_panel, s_cn2, false, part,
+                             tid, sh.local);
         if (SH && nchunks > 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's own column updates are out before the next panel reads them
             __syncthreads();
@@ -889,7 +1030,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_qr_large(double2* __restrict__ 
                                                           const int* __restrict__ large_ids, int* __restrict__ perm,
                                                           double* __restrict__ zero2_out, double cut2,
                                                           int* __restrict__ rank_host, int NW, char* __restrict__ qr_box,
-                                                          unsigned* __restrict__ qr_sync, int nl, int nx) {
+                                                          unsigned* __restrict__ qr_sync, int nl, int nx, int part_off) {
     extern __shared__ double2 g_lds[];
     __shared__ double s_piv[2];
     __shared__ int s_col[64 * JAC_MAXEL];
@@ -936,17 +1077,20 @@ __global__ __launch_bounds__(JAC_THREADS) void k_qr_large(double2* __restrict__ 
         sh.local = s_qlocal > 0;
         // (a timed-out wait has raised the failure word: the master's and the helpers' first hand-off see it and give up)
     }
+    // LDS beside the panel for the partial sums of the shared chunks (qr_trailing_coop): blocks of up to 256 rows, when the launch
+    // reserved it (part_off = the panel's extent in complex elements)
+    double* part = (part_off > 0 && ((m0 + 15) & ~15) <= 256) ? (double*)(g_lds + part_off) : nullptr;
     if (role > 0) {
-        qr_helper(G + D.g_off, m0, m, n, X, mp, s_col, (double2*)g_lds, tid, sh);
+        qr_helper(G + D.g_off, m0, m, n, X, mp, s_col, (double2*)g_lds, tid, sh, part);
         return;
     }
     int rank;
     if (NW > 1) {
-        if (m0 <= 256) rank = qrcp_blocked<4, true>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh);
-        else rank = qrcp_blocked<8, true>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh);
+        if (m0 <= 256) rank = qrcp_blocked<4, true>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh, part);
+        else rank = qrcp_blocked<8, true>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh, part);
     } else {
-        if (m0 <= 256) rank = qrcp_blocked<4, false>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh);
-        else rank = qrcp_blocked<8, false>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh);
+        if (m0 <= 256) rank = qrcp_blocked<4, false>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh, part);
+        else rank = qrcp_blocked<8, false>(G + D.g_off, m0, m, n, X, mp, s_col, s_cn2, s_piv, (double2*)g_lds, tid, cut2, sh, part);
     }
     if (tid == 0) {
         rank_host[li] = rank;                       // host-pinned: the host sizes the Jacobi tournament with it (< 0: a hand-off timed out)
@@ -2378,7 +2522,13 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
     {
         int max_m0 = 0;
         for (int li = 0; li < nl; ++li) max_m0 = std::max(max_m0, (int)desc_host[large[li]].pad);
-        const size_t qr_lds = (size_t)16 * (((max_m0 + 15) & ~15) + 1) * sizeof(double2);
+        const size_t qr_panel_elems = (size_t)16 * (((max_m0 + 15) & ~15) + 1);
+        int min_m0 = 1 << 30;
+        for (int li = 0; li < nl; ++li) min_m0 = std::min(min_m0, (int)desc_host[large[li]].pad);
+        // + 64 KiB for the partial tiles of the cooperative trailing update, when some block is small enough to use them and the
+        // panel of the largest leaves the room
+        const bool coop = ((min_m0 + 15) & ~15) <= 256 && qr_panel_elems * sizeof(double2) + 65536 + 30720 <= 163840;
+        const size_t qr_lds = qr_panel_elems * sizeof(double2) + (coop ? 65536 : 0);
         // workgroups per block: the master + helpers for the trailing update (all co-resident: they wait for each other)
         int max_n0 = 0;
         for (int li = 0; li < nl; ++li) max_n0 = std::max(max_n0, (int)desc_host[large[li]].m);
@@ -2410,7 +2560,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         }
         const int qgrid_nx = NW > 1 ? qnx : 1;
         hipLaunchKernelGGL(k_qr_large, dim3((NW > 1 ? nl_pad : nl) * NW), dim3(JAC_THREADS), qr_lds, st, (double2*)G, (double2*)Vj, desc, d_ids,
-                           d_perm, d_zero, cut2, d_rank, NW, (char*)g_js.qr_box, d_qsync, nl, qgrid_nx);
+                           d_perm, d_zero, cut2, d_rank, NW, (char*)g_js.qr_box, d_qsync, nl, qgrid_nx, coop ? (int)qr_panel_elems : 0);
     }
     if (cut2 > 0.0) {        // the tournament is sized by the ranks the QR found: wait for them (one sync per call)
         HIP_TRY(hipEventRecord(g_js.ev_sweep[0], st));
