@@ -2537,10 +2537,10 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
         // comes back from memory (sc1), so a chunk's operand loads wait ~2 us each instead of an L2 hit: 202 x 202 blocks LOSE
         // (trailing 483 -> 655 us with four workgroups), 400 x 400 blocks gain (3.0 -> 2.3 ms).
         static const int env_nw = getenv("HTN_QR_NW") ? atoi(getenv("HTN_QR_NW")) : 0;      // (experiments: helpers at any size)
-        // Helpers: above 288 columns always (the trailing update dominates by far: 400 x 400 3.9 -> 2.5 ms); below, only while the
-        // kernels keep finding a block's workgroups on one XCD (202 x 202: 884 -> 764 us through the shared L2, but 964 us when
-        // every shared byte has to go through memory).
-        int NW = qr_single ? 1 : ((max_n0 > 288 || g_js.xcd_local) ? 4 : 1);
+        // Helpers (profiles/r03_ring_qr_phase_times.txt): from 160 columns on always (202 x 202: 855 us alone, 697 with four
+        // workgroups through memory, 623 through one XCD's L2; 400 x 400: 3.9 -> 2.5 ms); below, only while the kernels keep
+        // finding a block's workgroups on one XCD (100 x 100: 266 -> 253 us through the L2).
+        int NW = qr_single ? 1 : ((max_n0 >= 160 || g_js.xcd_local) ? 4 : 1);
         if (env_nw > 0 && !qr_single) NW = std::min(env_nw, 4);
         // placement: the workgroups of a block at grid positions of one residue mod 8 (see k_qr_large); the gaps count
         // against the co-residency bound like everything else
