@@ -3,8 +3,9 @@
 // Stands in for KrylovKit.eigsolve(f, x0, 1, :SR, Lanczos(krylovdim, tol, eager)) as MPSKit calls it
 // on the AC2 effective Hamiltonian (reached from src/HubbardFunctions.jl:1010).
 // All vectors live in HBM; per iteration the host sees only the new tridiagonal coefficients
-// (alpha_j, beta_j) -- one small D2H copy -- and solves the <= krylovdim x krylovdim tridiagonal
-// eigenproblem itself.  The vector kernels are HBM/L2-bandwidth bound (roofline "hbm").
+// (alpha_j, beta_j) -- a 32-byte record in coherent pinned memory -- and solves the <= krylovdim x krylovdim tridiagonal
+// eigenproblem itself.  The vector kernels are HBM / Infinity-Cache bandwidth bound for many rows (roofline "hbm") and
+// launch-bound for few.
 //
 // Reductions are two-stage with a fixed summation order (per-block partials, then one wave sums the
 // 64 partials with a butterfly), so results are bit-reproducible run to run and rank to rank.

@@ -2622,7 +2622,7 @@ extern "C" int htn_jacobi_svd_z(void* G, void* Vj, double* S, const htn_svd_bloc
             if (h_ring_sw[li] <= 0 && n_eff[li] >= 2) return fail_msg("htn_jacobi_svd_z: a hand-off of the ring Jacobi kernel timed out");
             used = std::max(used, (int)h_ring_sw[li] % 1000);
         }
-        {   // what the kernel saw of the placement steers the NEXT call's choice of QR helpers (below 288 columns they only pay
+        {   // what the kernel saw of the placement steers the NEXT call's choice of QR helpers (below 160 columns they only pay
             // when the block's workgroups share an L2)
             int all_local = n_xcd > 1 ? 1 : 0;
             for (int li = 0; li < nl; ++li)

@@ -144,9 +144,10 @@ int htn_lanczos_z(const htn_gemm_launch* stages_host, int32_t n_stages, int32_t 
  * sweep direction needs is the normalised G*J itself; the other factor is then a plain GEMM with M.
  * desc: device array of htn_svd_block, desc_host: the same array in host memory (may be NULL: then every block
  * runs on ONE CU; with it, QRCP blocks larger than one CU's LDS take the large-block path: panel-blocked pivoted QR
- * (helper workgroups share its trailing update above 288 columns), then the ring block Jacobi -- all sweeps in ONE launch,
+ * (helper workgroups share its trailing update from 160 columns on), then the ring block Jacobi -- all sweeps in ONE launch,
  * every block on several CUs whose LDS-resident column panels are handed round inside the launch (write-through stores +
- * epoch flags; bounded waits: a time-out is reported as an error of this call), convergence decided on the device; the
+ * epoch flags -- or stores kept in one XCD's L2 when all workgroups of the block read the same XCD id at run time; bounded
+ * waits: a time-out is reported as an error of this call), convergence decided on the device; the
  * small blocks run beside it on an internal second stream that joins `stream` before the call returns; the call blocks
  * the host until everything has converged, results stay on the device.  Blocks the ring cannot take fall back to the
  * pair-visit block Jacobi of ABI 2 (one launch per tournament round; sweeps_hint bounds its speculative enqueue));
