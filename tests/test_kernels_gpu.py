@@ -212,7 +212,10 @@ def test_jacobi_svd_matches_lapack(hip_ops, shapes, acc):
 
 @pytest.mark.parametrize("multi", [False, True])
 @pytest.mark.parametrize("shapes", [[(1, 1), (2, 3), (40, 40), (33, 57), (57, 33)], [(107, 107), (150, 93), (93, 150)],
-                                    [(230, 230), (60, 60), (300, 170), (129, 140)]])
+                                    [(230, 230), (60, 60), (300, 170), (129, 140)],
+                                    # <= 256 rows and >= 160 columns: the pivoted QR runs with helper workgroups AND with all 16
+                                    # waves of a workgroup on its chunks of the trailing update (qr_trailing_coop)
+                                    [(202, 202), (180, 200), (96, 210)]])
 def test_jacobi_svd_qr_preconditioned(hip_ops, shapes, multi):
     """HTN_SVD_QRCP: G0 (m0 x n0) -> (right singular vectors of G0) x Sigma, n0 x min(m0, n0), rows in the
     ORIGINAL column order of G0; few sweeps on graded spectra"""
